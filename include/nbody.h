@@ -1,0 +1,168 @@
+/*
+ * nbody.h — C-ABI of the MI355X (gfx950) all-pairs N-body engine, libnbody_hip.so.
+ *
+ * This is the drop-in boundary for the reference's GPU step. Reference paths below are
+ * relative to the reference's TestProject/ directory.
+ *
+ *   reference                                         replaced by
+ *   ------------------------------------------------  -----------------------------------
+ *   void simulate(float4*,float4*,float4*,int)         nbody_simulate()         (kernel.cuh:2,
+ *                                                                               kernel.cu:628-645)
+ *   kernel<<<>>> + tile_interaction + bodyInteractions nbody_accel_range() +    (kernel.cu:9-29,
+ *                                                      nbody_integrate_range()   55-65, 80-130)
+ *   cudaMalloc/cudaMemcpy/cudaFree/cudaMallocHost/...  nbody_malloc_device() ...  (main.cpp:250-283,
+ *     used by main() and compareHostToDevice()                                  352-366;
+ *                                                                               validation.cpp:61-81)
+ *   DT / EPS2 / THREADS_PER_BLOCK / TILE_WIDTH_FACTOR  nbody_ctx_set_params(),    (constants.h:11-12,
+ *                                                      nbody_ctx_set_kernel()      25-26)
+ *
+ * Conventions
+ *   - plain C, no C++ or torch types; every pointer named d_* is DEVICE memory, h_* host.
+ *   - bodies are the reference's AoS float4 {x, y, z, w = mass}; velocities/accelerations are
+ *     float4 with w carried as 0 (main.cpp:232-241, 271-283).
+ *   - every entry point returns NBODY_OK (0) or an error code; nbody_last_error() gives the
+ *     message of the calling thread's last failure. (The reference throws std::runtime_error
+ *     from simulate(), kernel.cu:633-641; include/nbody_compat.hpp turns the code back into that
+ *     exception for C++ callers.)
+ *   - nothing here falls back to a CPU path: without a usable HIP device every compute entry
+ *     fails with NBODY_ERR_HIP.
+ */
+#ifndef NBODY_H
+#define NBODY_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nbody_float4 {
+    float x, y, z, w;
+} nbody_float4;
+
+typedef struct nbody_double4 {
+    double x, y, z, w;
+} nbody_double4;
+
+typedef struct nbody_ctx nbody_ctx;
+
+enum {
+    NBODY_OK = 0,
+    NBODY_ERR_INVALID = 1, /* bad argument (null pointer, n < 0, range outside [0,n) ...) */
+    NBODY_ERR_HIP = 2,     /* a HIP runtime call failed / no device */
+    NBODY_ERR_CONFIG = 3,  /* unsupported kernel configuration */
+    NBODY_ERR_NOMEM = 4
+};
+
+/* Arithmetic flavour of the force kernel. */
+enum {
+    NBODY_KERNEL_FAST = 0,  /* packed fp32, v_rsq_f32, fma; tolerance-level parity            */
+    NBODY_KERNEL_STRICT = 1 /* the reference's operation order with IEEE sqrt/div, no fma    */
+                            /* contraction, j==i skipped: bit-identical to validation.cpp's  */
+                            /* arithmetic taken in Jacobi order                              */
+};
+
+/* constants.h:25-26 */
+#define NBODY_DEFAULT_EPS2 0.002f
+#define NBODY_DEFAULT_DT 0.1f
+
+/* ---- the reference boundary ------------------------------------------------------------ */
+
+/* Drop-in for `void simulate(float4* d_bodies, float4* d_accelerations, float4* d_velocity,
+ * int N)` (kernel.cuh:2; kernel.cu:628-645): one step on device 0's arrays, in place,
+ * SYNCHRONOUS (returns after the device has finished, like the reference's
+ * cudaDeviceSynchronize at kernel.cu:644). d_accelerations is pure output. Uses DT / EPS2 of
+ * constants.h:25-26 and the FAST kernel unless the process-wide default context was
+ * reconfigured through nbody_default_ctx(). N need not be a multiple of anything. */
+int nbody_simulate(nbody_float4* d_bodies, nbody_float4* d_accelerations, nbody_float4* d_velocity,
+                   int n);
+
+/* The context nbody_simulate() uses (created on first use, device 0). */
+int nbody_default_ctx(nbody_ctx** out);
+
+/* ---- contexts ---------------------------------------------------------------------------- */
+
+/* A context owns a device id, a stream and the slab workspace. `device` < 0 = current device. */
+int nbody_ctx_create(nbody_ctx** out, int device);
+int nbody_ctx_destroy(nbody_ctx* ctx);
+
+/* dt / eps2 (defaults: constants.h:25-26). eps2 must be > 0: like the reference's GPU kernel
+ * (kernel.cu:61-63) the FAST kernel evaluates the j == i pair, which is only an exact zero
+ * when the softening keeps 1/sqrt(d^3) finite. */
+int nbody_ctx_set_params(nbody_ctx* ctx, float dt, float eps2);
+
+/* kernel: NBODY_KERNEL_*; tile: LDS tile in bodies (0 = default 1024; the reference's
+ * THREADS_PER_BLOCK*TILE_WIDTH_FACTOR, constants.h:11-12, is 32); bodies_per_lane: register
+ * blocking (0 = default 4); jsplit: source-range slabs per launch (0 = auto from N). */
+int nbody_ctx_set_kernel(nbody_ctx* ctx, int kernel, int tile, int bodies_per_lane, int jsplit);
+
+/* Launch on this HIP stream (a hipStream_t passed as void*; NULL = the context's own stream). */
+int nbody_ctx_set_stream(nbody_ctx* ctx, void* hip_stream);
+
+/* Pre-size the slab workspace for up to n_targets bodies so later calls never allocate. */
+int nbody_ctx_reserve(nbody_ctx* ctx, int n_targets);
+
+/* ---- stepping ---------------------------------------------------------------------------- */
+
+/* `steps` whole steps on [0,n): forces from the positions at the start of each step, then
+ * v += (0.5f*dt)*a ; x += dt*v (validation.cpp:40-49 == kernel.cu:116-129). ASYNCHRONOUS on the
+ * context's stream: no host synchronisation, the caller syncs (nbody_ctx_sync / its stream). */
+int nbody_step(nbody_ctx* ctx, nbody_float4* d_bodies, nbody_float4* d_accelerations,
+               nbody_float4* d_velocity, int n, int steps);
+
+/* Accelerations of targets [i0,i1) from sources [j0,j1) of d_bodies (absolute indices into one
+ * array of at least max(i1,j1) bodies). d_acc_out has i1-i0 entries. accumulate != 0 continues
+ * the sums already in d_acc_out (STRICT: continues the sequential sum exactly). Asynchronous.
+ * This is what a rank of the sharded multi-GPU step calls for its local and remote blocks. */
+int nbody_accel_range(nbody_ctx* ctx, const nbody_float4* d_bodies, nbody_float4* d_acc_out, int i0,
+                      int i1, int j0, int j1, int accumulate);
+
+/* Integrate bodies [i0,i1): d_bodies is the whole array (indexed absolutely), d_velocity and
+ * d_acc hold the i1-i0 own entries. Asynchronous. */
+int nbody_integrate_range(nbody_ctx* ctx, nbody_float4* d_bodies, nbody_float4* d_velocity,
+                          const nbody_float4* d_acc, int i0, int i1);
+
+int nbody_ctx_sync(nbody_ctx* ctx);
+
+/* ---- fp64 variant (the build's own; the reference has no double path) -------------------- */
+int nbody_step_f64(nbody_ctx* ctx, nbody_double4* d_bodies, nbody_double4* d_accelerations,
+                   nbody_double4* d_velocity, int n, int steps, double dt, double eps2);
+
+/* ---- memory helpers (what main.cpp / validation.cpp use the CUDA runtime for) ------------ */
+int nbody_device_count(int* count);
+int nbody_malloc_device(void** d_ptr, size_t bytes);   /* cudaMalloc      main.cpp:278-279,353 */
+int nbody_free_device(void* d_ptr);                    /* cudaFree        main.cpp:358-363     */
+int nbody_malloc_host(void** h_ptr, size_t bytes);     /* cudaMallocHost  main.cpp:250-252     */
+int nbody_free_host(void* h_ptr);                      /* cudaFreeHost    main.cpp:364-366     */
+int nbody_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes); /* main.cpp:282-283,354   */
+int nbody_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes); /* validation.cpp:79-81   */
+int nbody_device_synchronize(void);                    /* cudaDeviceSynchronize validation.cpp:77 */
+
+/* ---- host-side helpers with the reference's meaning (utils.h / validation.h) ------------- */
+/* utils.cpp:30-37: x,y,z in U(-1e5,1e5), w in U(1e5,1e9), 4 libc rand() draws per body in
+ * x,y,z,w order. */
+void nbody_fill_with_random4(nbody_float4* h_v, int n);
+/* utils.cpp:19-27 */
+void nbody_fill_with_zeroes4(nbody_float4* h_v, int n);
+/* Portable, seeded generators for reproducible cross-machine inputs (libc rand() is not:
+ * RAND_MAX differs between libcs). init: 0 = the reference's uniform cube and mass range,
+ * 1 = Plummer sphere (a = 1, total mass 1, G = 1), cold start. */
+int nbody_fill_seeded(nbody_float4* h_bodies, int n, int init, unsigned long long seed);
+/* validation.cpp:143-164 and 106-122, returning the number of bodies the reference would have
+ * printed "Problem at body" for instead of printing them. */
+int nbody_verify_still_bodies(const nbody_float4* h_v, const nbody_float4* h_x, int n);
+int nbody_verify_equality4(const nbody_float4* h_v, const nbody_float4* h_x, int n);
+
+/* ---- diagnostics ------------------------------------------------------------------------- */
+const char* nbody_last_error(void);
+/* e.g. "nbody_hip 0.1 gfx950 fast=lds-packed bpl4 tile1024" */
+const char* nbody_version(void);
+/* What the context resolved for a problem of n targets x m sources: slabs per launch, grid
+ * blocks, LDS bytes per block. Any out pointer may be NULL. */
+int nbody_ctx_launch_info(nbody_ctx* ctx, int n_targets, int n_sources, int* jsplit, int* blocks,
+                          int* lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBODY_H */

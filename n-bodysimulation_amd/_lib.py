@@ -1,0 +1,97 @@
+"""ctypes binding of ``libnbody_hip.so`` (the C-ABI declared in ``include/nbody.h``).
+
+The library is the product: there is no Python or CPU fallback. If it has not been built
+(``python -c 'import __graft_entry__ as g; g.build()'`` or ``make -C n-bodysimulation_amd/csrc``)
+loading fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnbody_hip.so")
+
+OK = 0
+ERR_INVALID = 1
+ERR_HIP = 2
+ERR_CONFIG = 3
+ERR_NOMEM = 4
+
+KERNEL_FAST = 0
+KERNEL_STRICT = 1
+
+DEFAULT_EPS2 = 0.002  # constants.h:25
+DEFAULT_DT = 0.1      # constants.h:26
+
+
+class NBodyError(RuntimeError):
+    """Raised for any non-zero status of the C-ABI (the reference throws std::runtime_error
+    from simulate(): TestProject/kernel.cu:633-641)."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"nbody error {code}: {msg}")
+        self.code = code
+
+
+# every symbol include/nbody.h declares, with its signature
+_p = C.c_void_p
+_SIGNATURES = {
+    "nbody_simulate": (C.c_int, [_p, _p, _p, C.c_int]),
+    "nbody_default_ctx": (C.c_int, [C.POINTER(_p)]),
+    "nbody_ctx_create": (C.c_int, [C.POINTER(_p), C.c_int]),
+    "nbody_ctx_destroy": (C.c_int, [_p]),
+    "nbody_ctx_set_params": (C.c_int, [_p, C.c_float, C.c_float]),
+    "nbody_ctx_set_kernel": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "nbody_ctx_set_stream": (C.c_int, [_p, _p]),
+    "nbody_ctx_reserve": (C.c_int, [_p, C.c_int]),
+    "nbody_step": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int]),
+    "nbody_accel_range": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "nbody_integrate_range": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int]),
+    "nbody_ctx_sync": (C.c_int, [_p]),
+    "nbody_step_f64": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_double, C.c_double]),
+    "nbody_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "nbody_malloc_device": (C.c_int, [C.POINTER(_p), C.c_size_t]),
+    "nbody_free_device": (C.c_int, [_p]),
+    "nbody_malloc_host": (C.c_int, [C.POINTER(_p), C.c_size_t]),
+    "nbody_free_host": (C.c_int, [_p]),
+    "nbody_memcpy_h2d": (C.c_int, [_p, _p, C.c_size_t]),
+    "nbody_memcpy_d2h": (C.c_int, [_p, _p, C.c_size_t]),
+    "nbody_device_synchronize": (C.c_int, []),
+    "nbody_fill_with_random4": (None, [_p, C.c_int]),
+    "nbody_fill_with_zeroes4": (None, [_p, C.c_int]),
+    "nbody_fill_seeded": (C.c_int, [_p, C.c_int, C.c_int, C.c_ulonglong]),
+    "nbody_verify_still_bodies": (C.c_int, [_p, _p, C.c_int]),
+    "nbody_verify_equality4": (C.c_int, [_p, _p, C.c_int]),
+    "nbody_last_error": (C.c_char_p, []),
+    "nbody_version": (C.c_char_p, []),
+    "nbody_ctx_launch_info": (C.c_int, [_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                         C.POINTER(C.c_int)]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build the HIP library first "
+                "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def check(rc: int) -> None:
+    if rc != OK:
+        raise NBodyError(rc, load().nbody_last_error().decode(errors="replace"))

@@ -1,0 +1,511 @@
+// nbody_api.hip — implementation of include/nbody.h (libnbody_hip.so) for gfx950.
+//
+// Host launchers for the kernels in nbody_kernels.hip.h plus the small amount of host logic the
+// reference keeps in simulate() (TestProject/kernel.cu:628-645): launch-shape selection and
+// error reporting. No CPU compute path exists in this file on purpose.
+#include "nbody.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "nbody_kernels.hip.h"
+
+static_assert(sizeof(nbody_float4) == sizeof(float4) && alignof(float4) == 16, "float4 layout");
+static_assert(sizeof(nbody_double4) == sizeof(double4), "double4 layout");
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(NBODY_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                \
+    } while (0)
+
+constexpr int kMaxSplit = 32;
+
+}  // namespace
+
+struct nbody_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    float dt = NBODY_DEFAULT_DT;
+    float eps2 = NBODY_DEFAULT_EPS2;
+    int kernel = NBODY_KERNEL_FAST;
+    int tile = 0;    // 0 = auto
+    int bpl = 0;     // 0 = auto
+    int jsplit = 0;  // 0 = auto
+    int num_cu = 256;
+    void* slabs = nullptr;     // workspace: jsplit slabs of n_targets float4 (or double4)
+    size_t slab_bytes = 0;
+};
+
+namespace {
+
+using P2 = nbk::MathPacked<2>;
+using P4 = nbk::MathPacked<4>;
+using S1 = nbk::MathScalar<1>;
+
+struct Shape {
+    int bpl, tile, jsplit, blocks_x;
+};
+
+// Launch shape for (n_targets x n_sources). The reference hard-codes 32 threads/block and a
+// 32-body tile (constants.h:11-12); here the block is 256 threads, each lane holds `bpl`
+// targets, and the source range is cut into `jsplit` slabs so that the grid has at least
+// ~8 workgroups per CU (measured on MI355X: 4 slabs reach 99% of the 16-slab rate at
+// N=262144; more blocks mainly smooth the tail).
+Shape resolve_shape(const nbody_ctx* c, int n_targets, int n_sources)
+{
+    Shape s{};
+    s.bpl = c->bpl ? c->bpl : (n_targets >= 32768 ? 4 : (n_targets >= 8192 ? 2 : 1));
+    s.tile = c->tile ? c->tile : 1024;
+    if (s.tile == 2048) s.bpl = 4;  // the 2048-body tile is only instantiated for 4 targets per lane
+    s.blocks_x = (n_targets + nbk::kWG * s.bpl - 1) / (nbk::kWG * s.bpl);
+    if (c->kernel == NBODY_KERNEL_STRICT) {
+        s.bpl = 1;
+        s.tile = 1024;
+        s.jsplit = 1;
+        s.blocks_x = (n_targets + nbk::kWG - 1) / nbk::kWG;
+        return s;
+    }
+    if (c->jsplit) {
+        s.jsplit = c->jsplit;
+    } else {
+        const int want = 8 * c->num_cu;
+        int js = 1;
+        while (s.blocks_x * js < want && js < kMaxSplit) js *= 2;
+        // keep at least two tiles per slab
+        const int ntile = (n_sources + s.tile - 1) / s.tile;
+        while (js > 1 && ntile / js < 2) js /= 2;
+        s.jsplit = js;
+    }
+    if (s.jsplit < 1) s.jsplit = 1;
+    if (s.jsplit > kMaxSplit) s.jsplit = kMaxSplit;
+    return s;
+}
+
+int ensure_slabs(nbody_ctx* c, size_t bytes)
+{
+    if (bytes <= c->slab_bytes) return NBODY_OK;
+    if (c->slabs) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipFree(c->slabs));
+        c->slabs = nullptr;
+        c->slab_bytes = 0;
+    }
+    HIP_TRY(hipMalloc(&c->slabs, bytes));
+    c->slab_bytes = bytes;
+    return NBODY_OK;
+}
+
+template <class M, int TILE>
+void launch_lds(const nbk::ForceParams& p, dim3 grid, hipStream_t st)
+{
+    nbk::force_lds<M, TILE, 8, 1><<<grid, nbk::kWG, 0, st>>>(p);
+}
+
+int launch_force(nbody_ctx* c, const Shape& s, const nbk::ForceParams& p)
+{
+    if (p.i1 <= p.i0) return NBODY_OK;
+    if (c->kernel == NBODY_KERNEL_STRICT) {
+        nbk::force_strict<1024><<<dim3(s.blocks_x), nbk::kWG, 0, c->stream>>>(p);
+        HIP_TRY(hipGetLastError());
+        return NBODY_OK;
+    }
+    const dim3 grid(s.blocks_x, s.jsplit);
+    const int key = s.bpl * 10000 + s.tile;
+    switch (key) {
+        case 1 * 10000 + 256: nbk::force_lds<S1, 256, 8, 1><<<grid, nbk::kWG, 0, c->stream>>>(p); break;
+        case 1 * 10000 + 512: nbk::force_lds<S1, 512, 8, 1><<<grid, nbk::kWG, 0, c->stream>>>(p); break;
+        case 1 * 10000 + 1024: nbk::force_lds<S1, 1024, 8, 1><<<grid, nbk::kWG, 0, c->stream>>>(p); break;
+        case 2 * 10000 + 256: launch_lds<P2, 256>(p, grid, c->stream); break;
+        case 2 * 10000 + 512: launch_lds<P2, 512>(p, grid, c->stream); break;
+        case 2 * 10000 + 1024: launch_lds<P2, 1024>(p, grid, c->stream); break;
+        case 4 * 10000 + 256: launch_lds<P4, 256>(p, grid, c->stream); break;
+        case 4 * 10000 + 512: launch_lds<P4, 512>(p, grid, c->stream); break;
+        case 4 * 10000 + 1024: launch_lds<P4, 1024>(p, grid, c->stream); break;
+        case 4 * 10000 + 2048: launch_lds<P4, 2048>(p, grid, c->stream); break;
+        default:
+            return fail(NBODY_ERR_CONFIG, "no force kernel for bodies_per_lane=%d tile=%d", s.bpl, s.tile);
+    }
+    HIP_TRY(hipGetLastError());
+    return NBODY_OK;
+}
+
+int check_ctx(const nbody_ctx* c)
+{
+    if (!c) return fail(NBODY_ERR_INVALID, "null context");
+    return NBODY_OK;
+}
+
+std::mutex g_default_mu;
+nbody_ctx* g_default = nullptr;
+
+}  // namespace
+
+extern "C" {
+
+const char* nbody_last_error(void) { return g_err; }
+
+const char* nbody_version(void)
+{
+    return "nbody_hip 0.1 gfx950 fast=lds-packed(bpl4,tile1024,u8) strict=ieee-seq f64=lds";
+}
+
+int nbody_device_count(int* count)
+{
+    if (!count) return fail(NBODY_ERR_INVALID, "null count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(NBODY_ERR_HIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return NBODY_OK;
+}
+
+int nbody_ctx_create(nbody_ctx** out, int device)
+{
+    if (!out) return fail(NBODY_ERR_INVALID, "null out");
+    *out = nullptr;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail(NBODY_ERR_HIP, "no HIP device visible");
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    if (device >= ndev) return fail(NBODY_ERR_INVALID, "device %d out of range (%d devices)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    nbody_ctx* c = new (std::nothrow) nbody_ctx();
+    if (!c) return fail(NBODY_ERR_NOMEM, "out of host memory");
+    c->device = device;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(NBODY_ERR_HIP, "hipGetDeviceProperties failed: %s", hipGetErrorString(e));
+    }
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    e = hipStreamCreate(&c->own_stream);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(NBODY_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return NBODY_OK;
+}
+
+int nbody_ctx_destroy(nbody_ctx* c)
+{
+    if (!c) return NBODY_OK;
+    hipSetDevice(c->device);
+    if (c->slabs) hipFree(c->slabs);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    delete c;
+    return NBODY_OK;
+}
+
+int nbody_default_ctx(nbody_ctx** out)
+{
+    if (!out) return fail(NBODY_ERR_INVALID, "null out");
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    if (!g_default) {
+        int rc = nbody_ctx_create(&g_default, 0);  // the reference hard-codes device 0 (kernel.cu:630)
+        if (rc != NBODY_OK) return rc;
+    }
+    *out = g_default;
+    return NBODY_OK;
+}
+
+int nbody_ctx_set_params(nbody_ctx* c, float dt, float eps2)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (!(eps2 > 0.0f) || !std::isfinite(eps2)) return fail(NBODY_ERR_INVALID, "eps2 must be finite and > 0 (got %g)", eps2);
+    if (!std::isfinite(dt)) return fail(NBODY_ERR_INVALID, "dt must be finite (got %g)", dt);
+    c->dt = dt;
+    c->eps2 = eps2;
+    return NBODY_OK;
+}
+
+int nbody_ctx_set_kernel(nbody_ctx* c, int kernel, int tile, int bodies_per_lane, int jsplit)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (kernel != NBODY_KERNEL_FAST && kernel != NBODY_KERNEL_STRICT)
+        return fail(NBODY_ERR_CONFIG, "unknown kernel %d", kernel);
+    if (tile != 0 && tile != 256 && tile != 512 && tile != 1024 && tile != 2048)
+        return fail(NBODY_ERR_CONFIG, "tile must be 0 (auto), 256, 512, 1024 or 2048 (got %d)", tile);
+    if (bodies_per_lane != 0 && bodies_per_lane != 1 && bodies_per_lane != 2 && bodies_per_lane != 4)
+        return fail(NBODY_ERR_CONFIG, "bodies_per_lane must be 0 (auto), 1, 2 or 4 (got %d)", bodies_per_lane);
+    if (tile == 2048 && bodies_per_lane != 4 && bodies_per_lane != 0)
+        return fail(NBODY_ERR_CONFIG, "tile 2048 is built for bodies_per_lane 4 only");
+    if (jsplit < 0 || jsplit > kMaxSplit) return fail(NBODY_ERR_CONFIG, "jsplit must be in [0,%d] (got %d)", kMaxSplit, jsplit);
+    c->kernel = kernel;
+    c->tile = tile;
+    c->bpl = bodies_per_lane;
+    c->jsplit = jsplit;
+    return NBODY_OK;
+}
+
+int nbody_ctx_set_stream(nbody_ctx* c, void* hip_stream)
+{
+    if (int rc = check_ctx(c)) return rc;
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return NBODY_OK;
+}
+
+int nbody_ctx_reserve(nbody_ctx* c, int n_targets)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (n_targets < 0) return fail(NBODY_ERR_INVALID, "n_targets < 0");
+    HIP_TRY(hipSetDevice(c->device));
+    return ensure_slabs(c, (size_t)kMaxSplit * (size_t)n_targets * sizeof(float4));
+}
+
+int nbody_ctx_launch_info(nbody_ctx* c, int n_targets, int n_sources, int* jsplit, int* blocks, int* lds_bytes)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (n_targets < 0 || n_sources < 0) return fail(NBODY_ERR_INVALID, "negative size");
+    const Shape s = resolve_shape(c, n_targets, n_sources);
+    if (jsplit) *jsplit = s.jsplit;
+    if (blocks) *blocks = s.blocks_x * s.jsplit;
+    if (lds_bytes) *lds_bytes = (c->kernel == NBODY_KERNEL_STRICT ? 1 : 2) * s.tile * (int)sizeof(float4);
+    return NBODY_OK;
+}
+
+int nbody_accel_range(nbody_ctx* c, const nbody_float4* d_bodies, nbody_float4* d_acc_out, int i0, int i1,
+                      int j0, int j1, int accumulate)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (i0 < 0 || i1 < i0 || j0 < 0 || j1 < j0) return fail(NBODY_ERR_INVALID, "bad range i[%d,%d) j[%d,%d)", i0, i1, j0, j1);
+    const int nt = i1 - i0;
+    if (nt == 0) return NBODY_OK;
+    if (!d_bodies || !d_acc_out) return fail(NBODY_ERR_INVALID, "null device pointer");
+    HIP_TRY(hipSetDevice(c->device));
+    const Shape s = resolve_shape(c, nt, j1 - j0);
+    nbk::ForceParams p{};
+    p.x = reinterpret_cast<const float4*>(d_bodies);
+    p.i0 = i0; p.i1 = i1; p.j0 = j0; p.j1 = j1;
+    p.eps2 = c->eps2;
+    if (s.jsplit == 1) {
+        p.out = reinterpret_cast<float4*>(d_acc_out);
+        p.slab_stride = 0;
+        p.accumulate = accumulate ? 1 : 0;
+        if (j1 == j0 && !accumulate) {
+            HIP_TRY(hipMemsetAsync(d_acc_out, 0, (size_t)nt * sizeof(float4), c->stream));
+            return NBODY_OK;
+        }
+        return launch_force(c, s, p);
+    }
+    if (int rc = ensure_slabs(c, (size_t)s.jsplit * nt * sizeof(float4))) return rc;
+    p.out = static_cast<float4*>(c->slabs);
+    p.slab_stride = nt;
+    p.accumulate = 0;
+    if (int rc = launch_force(c, s, p)) return rc;
+    nbk::ReduceParams r{};
+    r.out = reinterpret_cast<float4*>(d_acc_out);
+    r.slabs = static_cast<const float4*>(c->slabs);
+    r.nslab = s.jsplit;
+    r.slab_stride = nt;
+    r.n = nt;
+    r.accumulate = accumulate ? 1 : 0;
+    nbk::reduce_slabs<<<(nt + nbk::kWG - 1) / nbk::kWG, nbk::kWG, 0, c->stream>>>(r);
+    HIP_TRY(hipGetLastError());
+    return NBODY_OK;
+}
+
+int nbody_integrate_range(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_velocity, const nbody_float4* d_acc,
+                          int i0, int i1)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (i0 < 0 || i1 < i0) return fail(NBODY_ERR_INVALID, "bad range [%d,%d)", i0, i1);
+    const int n = i1 - i0;
+    if (n == 0) return NBODY_OK;
+    if (!d_bodies || !d_velocity || !d_acc) return fail(NBODY_ERR_INVALID, "null device pointer");
+    HIP_TRY(hipSetDevice(c->device));
+    nbk::IntegrateParams q{};
+    q.x = reinterpret_cast<float4*>(d_bodies) + i0;
+    q.v = reinterpret_cast<float4*>(d_velocity);
+    q.a = const_cast<float4*>(reinterpret_cast<const float4*>(d_acc));
+    q.slabs = nullptr;
+    q.nslab = 0;
+    q.slab_stride = 0;
+    q.n = n;
+    q.dt = c->dt;
+    nbk::integrate<<<(n + nbk::kWG - 1) / nbk::kWG, nbk::kWG, 0, c->stream>>>(q);
+    HIP_TRY(hipGetLastError());
+    return NBODY_OK;
+}
+
+int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_accelerations, nbody_float4* d_velocity, int n,
+               int steps)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (n < 0 || steps < 0) return fail(NBODY_ERR_INVALID, "n=%d steps=%d", n, steps);
+    if (n == 0 || steps == 0) return NBODY_OK;  // an empty system is a no-op, whatever the pointers
+    if (!d_bodies || !d_accelerations || !d_velocity) return fail(NBODY_ERR_INVALID, "null device pointer");
+    HIP_TRY(hipSetDevice(c->device));
+    const Shape s = resolve_shape(c, n, n);
+    nbk::ForceParams p{};
+    p.x = reinterpret_cast<const float4*>(d_bodies);
+    p.i0 = 0; p.i1 = n; p.j0 = 0; p.j1 = n;
+    p.eps2 = c->eps2;
+    p.accumulate = 0;
+    nbk::IntegrateParams q{};
+    q.x = reinterpret_cast<float4*>(d_bodies);
+    q.v = reinterpret_cast<float4*>(d_velocity);
+    q.a = reinterpret_cast<float4*>(d_accelerations);
+    q.n = n;
+    q.dt = c->dt;
+    if (s.jsplit == 1) {
+        p.out = q.a;
+        p.slab_stride = 0;
+        q.slabs = nullptr;
+        q.nslab = 0;
+        q.slab_stride = 0;
+    } else {
+        if (int rc = ensure_slabs(c, (size_t)s.jsplit * n * sizeof(float4))) return rc;
+        p.out = static_cast<float4*>(c->slabs);
+        p.slab_stride = n;
+        q.slabs = static_cast<const float4*>(c->slabs);
+        q.nslab = s.jsplit;
+        q.slab_stride = n;
+    }
+    const int iblocks = (n + nbk::kWG - 1) / nbk::kWG;
+    for (int k = 0; k < steps; ++k) {
+        if (int rc = launch_force(c, s, p)) return rc;
+        nbk::integrate<<<iblocks, nbk::kWG, 0, c->stream>>>(q);
+    }
+    HIP_TRY(hipGetLastError());
+    return NBODY_OK;
+}
+
+int nbody_ctx_sync(nbody_ctx* c)
+{
+    if (int rc = check_ctx(c)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return NBODY_OK;
+}
+
+int nbody_simulate(nbody_float4* d_bodies, nbody_float4* d_accelerations, nbody_float4* d_velocity, int n)
+{
+    nbody_ctx* c = nullptr;
+    if (int rc = nbody_default_ctx(&c)) return rc;
+    if (int rc = nbody_step(c, d_bodies, d_accelerations, d_velocity, n, 1)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));  // simulate() is synchronous: kernel.cu:644
+    return NBODY_OK;
+}
+
+int nbody_step_f64(nbody_ctx* c, nbody_double4* d_bodies, nbody_double4* d_accelerations, nbody_double4* d_velocity,
+                   int n, int steps, double dt, double eps2)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (!d_bodies || !d_accelerations || !d_velocity) return fail(NBODY_ERR_INVALID, "null device pointer");
+    if (n < 0 || steps < 0) return fail(NBODY_ERR_INVALID, "n=%d steps=%d", n, steps);
+    if (!(eps2 > 0.0)) return fail(NBODY_ERR_INVALID, "eps2 must be > 0");
+    if (n == 0 || steps == 0) return NBODY_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    constexpr int BPL = 2, TILE = 512;
+    const int blocks_x = (n + nbk::kWG * BPL - 1) / (nbk::kWG * BPL);
+    int js = c->jsplit;
+    if (!js) {
+        js = 1;
+        while (blocks_x * js < 8 * c->num_cu && js < kMaxSplit) js *= 2;
+        const int ntile = (n + TILE - 1) / TILE;
+        while (js > 1 && ntile / js < 2) js /= 2;
+    }
+    if (int rc = ensure_slabs(c, (size_t)js * n * sizeof(double4))) return rc;
+    nbk::ForceParamsF64 p{};
+    p.x = reinterpret_cast<const double4*>(d_bodies);
+    p.out = static_cast<double4*>(c->slabs);
+    p.n = n;
+    p.slab_stride = n;
+    p.eps2 = eps2;
+    nbk::IntegrateParamsF64 q{};
+    q.x = reinterpret_cast<double4*>(d_bodies);
+    q.v = reinterpret_cast<double4*>(d_velocity);
+    q.a = reinterpret_cast<double4*>(d_accelerations);
+    q.slabs = static_cast<const double4*>(c->slabs);
+    q.nslab = js;
+    q.slab_stride = n;
+    q.n = n;
+    q.dt = dt;
+    for (int k = 0; k < steps; ++k) {
+        nbk::force_f64<BPL, TILE><<<dim3(blocks_x, js), nbk::kWG, 0, c->stream>>>(p);
+        nbk::integrate_f64<<<(n + nbk::kWG - 1) / nbk::kWG, nbk::kWG, 0, c->stream>>>(q);
+    }
+    HIP_TRY(hipGetLastError());
+    return NBODY_OK;
+}
+
+// ---- memory helpers ---------------------------------------------------------------------
+
+int nbody_malloc_device(void** d_ptr, size_t bytes)
+{
+    if (!d_ptr) return fail(NBODY_ERR_INVALID, "null d_ptr");
+    *d_ptr = nullptr;
+    HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 1));
+    return NBODY_OK;
+}
+
+int nbody_free_device(void* d_ptr)
+{
+    if (d_ptr) HIP_TRY(hipFree(d_ptr));
+    return NBODY_OK;
+}
+
+int nbody_malloc_host(void** h_ptr, size_t bytes)
+{
+    if (!h_ptr) return fail(NBODY_ERR_INVALID, "null h_ptr");
+    *h_ptr = nullptr;
+    HIP_TRY(hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return NBODY_OK;
+}
+
+int nbody_free_host(void* h_ptr)
+{
+    if (h_ptr) HIP_TRY(hipHostFree(h_ptr));
+    return NBODY_OK;
+}
+
+int nbody_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes)
+{
+    if (bytes && (!d_dst || !h_src)) return fail(NBODY_ERR_INVALID, "null pointer");
+    HIP_TRY(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+    return NBODY_OK;
+}
+
+int nbody_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes)
+{
+    if (bytes && (!h_dst || !d_src)) return fail(NBODY_ERR_INVALID, "null pointer");
+    HIP_TRY(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return NBODY_OK;
+}
+
+int nbody_device_synchronize(void)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    return NBODY_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,455 @@
+// nbody_kernels.hip.h — gfx950 (MI355X / CDNA4) device code for the all-pairs step.
+//
+// Replaces the reference's device side: bodyInteractions (TestProject/kernel.cu:9-29),
+// tile_interaction (kernel.cu:55-65) and kernel (kernel.cu:80-130). It is a new design, not a
+// translation:
+//   * force accumulation and integration are SEPARATE kernels; positions are only written
+//     by the integrate kernel after every force has been taken, so the step is Jacobi (the
+//     reference kernel's in-place update races between blocks: kernel.cu:94-129);
+//   * 256-thread workgroups (4 wave64), BPL target bodies per lane held in registers, the
+//     source bodies streamed through a double-buffered LDS tile that is filled with
+//     coalesced 16-byte loads and read back with broadcast ds_read_b128 (one LDS read
+//     feeds BPL pairs per lane);
+//   * the source range can be split over gridDim.y "slabs" so that small N still fills
+//     256 CUs; slabs are summed in a fixed order by the integrate kernel (deterministic,
+//     no float atomics).
+//
+// Two arithmetic flavours:
+//   fast   — d = fma chain, v_rsq_f32, f = m * rsq^3, fma accumulate (13 VALU ops / pair);
+//   strict — the reference's operation order with individually rounded IEEE ops
+//            (1.0f / sqrtf(d*d*d), no contraction, j == i skipped as validation.cpp:35 does),
+//            one target per lane, sources in index order: bit-identical to the CPU
+//            restatement of validation.cpp:28-52 in Jacobi order.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace nbk {
+
+constexpr int kWG = 256;  // threads per workgroup (4 wave64)
+
+struct ForceParams {
+    const float4* x;    // bodies {x,y,z,mass}; indexed absolutely over the whole system
+    float4* out;        // slab 0 of the output: out[s * slab_stride + (i - i0)]
+    int i0, i1;         // target bodies [i0, i1)
+    int j0, j1;         // source bodies [j0, j1)
+    int slab_stride;    // elements between slabs
+    int accumulate;     // start each sum from the value already in `out`
+    float eps2;
+};
+
+// ---------------------------------------------------------------------------------------
+// fast flavour
+// ---------------------------------------------------------------------------------------
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Scalar-lane maths: BPL independent targets per lane, one VALU op per target per step.
+// (hipcc's SLP pass still pairs some of these into v_pk_* ops on its own.)
+template <int BPL_>
+struct MathScalar {
+    static constexpr int BPL = BPL_;
+    float x[BPL], y[BPL], z[BPL];
+    float ax[BPL], ay[BPL], az[BPL];
+
+    __device__ __forceinline__ void set(int k, const float4 b)
+    {
+        x[k] = b.x; y[k] = b.y; z[k] = b.z;
+        ax[k] = 0.0f; ay[k] = 0.0f; az[k] = 0.0f;
+    }
+    __device__ __forceinline__ float4 acc(int k) const { return make_float4(ax[k], ay[k], az[k], 0.0f); }
+
+    __device__ __forceinline__ void pair(const float4 bj, const float eps2)
+    {
+#pragma unroll
+        for (int k = 0; k < BPL; ++k) {
+            const float rx = bj.x - x[k];
+            const float ry = bj.y - y[k];
+            const float rz = bj.z - z[k];
+            float d = __builtin_fmaf(rx, rx, eps2);
+            d = __builtin_fmaf(ry, ry, d);
+            d = __builtin_fmaf(rz, rz, d);
+            const float inv = __builtin_amdgcn_rsqf(d);  // v_rsq_f32, 1 ulp
+            const float inv2 = inv * inv;
+            const float mi = bj.w * inv;
+            const float f = inv2 * mi;
+            ax[k] = __builtin_fmaf(rx, f, ax[k]);
+            ay[k] = __builtin_fmaf(ry, f, ay[k]);
+            az[k] = __builtin_fmaf(rz, f, az[k]);
+        }
+    }
+};
+
+// Packed maths: targets 2k and 2k+1 share a 64-bit register pair per component, so the
+// subtract / fma / mul steps are v_pk_add_f32 / v_pk_fma_f32 / v_pk_mul_f32 (two pairs per
+// instruction, the source broadcast through op_sel); only v_rsq_f32 stays per pair.
+// 12 packed ops + 2 rsq for two pairs instead of 24 + 2.
+template <int BPL_>
+struct MathPacked {
+    static_assert(BPL_ % 2 == 0, "packed maths handles targets two at a time");
+    static constexpr int BPL = BPL_;
+    static constexpr int H = BPL / 2;
+    f32x2 x[H], y[H], z[H];
+    f32x2 ax[H], ay[H], az[H];
+
+    __device__ __forceinline__ void set(int k, const float4 b)
+    {
+        x[k >> 1][k & 1] = b.x; y[k >> 1][k & 1] = b.y; z[k >> 1][k & 1] = b.z;
+        ax[k >> 1][k & 1] = 0.0f; ay[k >> 1][k & 1] = 0.0f; az[k >> 1][k & 1] = 0.0f;
+    }
+    __device__ __forceinline__ float4 acc(int k) const
+    {
+        return make_float4(ax[k >> 1][k & 1], ay[k >> 1][k & 1], az[k >> 1][k & 1], 0.0f);
+    }
+
+    __device__ __forceinline__ void pair(const float4 bj, const float eps2)
+    {
+        const f32x2 bx = {bj.x, bj.x}, by = {bj.y, bj.y}, bz = {bj.z, bj.z}, bm = {bj.w, bj.w};
+        const f32x2 e2 = {eps2, eps2};
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            const f32x2 rx = bx - x[k];
+            const f32x2 ry = by - y[k];
+            const f32x2 rz = bz - z[k];
+            f32x2 d = __builtin_elementwise_fma(rx, rx, e2);
+            d = __builtin_elementwise_fma(ry, ry, d);
+            d = __builtin_elementwise_fma(rz, rz, d);
+            f32x2 inv;
+            inv.x = __builtin_amdgcn_rsqf(d.x);
+            inv.y = __builtin_amdgcn_rsqf(d.y);
+            const f32x2 inv2 = inv * inv;
+            const f32x2 mi = bm * inv;
+            const f32x2 f = inv2 * mi;
+            ax[k] = __builtin_elementwise_fma(rx, f, ax[k]);
+            ay[k] = __builtin_elementwise_fma(ry, f, ay[k]);
+            az[k] = __builtin_elementwise_fma(rz, f, az[k]);
+        }
+    }
+};
+
+// Source range of slab s when [j0,j1) is cut into `nslab` runs of whole tiles.
+__device__ __forceinline__ void slab_range(int j0, int j1, int tile, int nslab, int s, int& a, int& b)
+{
+    const int ntile = (j1 - j0 + tile - 1) / tile;
+    const int per = (ntile + nslab - 1) / nslab;
+    a = j0 + s * per * tile;
+    b = a + per * tile;
+    if (a > j1) a = j1;
+    if (b > j1) b = j1;
+}
+
+template <class M>
+__device__ __forceinline__ void load_targets(const ForceParams& p, int ibase, M& t)
+{
+#pragma unroll
+    for (int k = 0; k < M::BPL; ++k) {
+        int i = ibase + k * kWG + (int)threadIdx.x;
+        if (i > p.i1 - 1) i = p.i1 - 1;  // clamp: the surplus lanes compute a copy, never store
+        t.set(k, p.x[i]);
+    }
+}
+
+template <class M>
+__device__ __forceinline__ void store_targets(const ForceParams& p, int ibase, int slab, const M& t)
+{
+    float4* out = p.out + (size_t)slab * p.slab_stride;
+#pragma unroll
+    for (int k = 0; k < M::BPL; ++k) {
+        const int i = ibase + k * kWG + (int)threadIdx.x;
+        if (i < p.i1) {
+            float4 a = t.acc(k);
+            if (p.accumulate) {
+                const float4 o = out[i - p.i0];
+                a.x += o.x; a.y += o.y; a.z += o.z;
+            }
+            out[i - p.i0] = a;
+        }
+    }
+}
+
+// LDS-tiled force kernel. grid = (ceil((i1-i0) / (256*BPL)), nslab).
+template <class M, int TILE, int UNROLL, int MINW>
+__global__ void __launch_bounds__(kWG, MINW) force_lds(const ForceParams p)
+{
+    static_assert(TILE % kWG == 0, "tile must be a multiple of the workgroup");
+    constexpr int LPT = TILE / kWG;  // float4 loads per thread per tile
+    __shared__ float4 sh[2][TILE];
+
+    const int tid = threadIdx.x;
+    const int ibase = p.i0 + blockIdx.x * (kWG * M::BPL);
+    M t;
+    load_targets(p, ibase, t);
+
+    int ja, jb;
+    slab_range(p.j0, p.j1, TILE, gridDim.y, blockIdx.y, ja, jb);
+
+    // A source past the end is replaced by a massless body: it adds exactly +-0.
+    float4 pre[LPT];
+    auto fetch = [&](int jt) {
+#pragma unroll
+        for (int l = 0; l < LPT; ++l) {
+            const int j = jt + l * kWG + tid;
+            pre[l] = (j < jb) ? p.x[j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    };
+
+    if (ja < jb) fetch(ja);
+    int buf = 0;
+    for (int jt = ja; jt < jb; jt += TILE, buf ^= 1) {
+#pragma unroll
+        for (int l = 0; l < LPT; ++l) sh[buf][l * kWG + tid] = pre[l];
+        __syncthreads();  // one barrier per tile: the other buffer is only rewritten after
+                          // every wave has passed the NEXT barrier, i.e. finished this tile
+        if (jt + TILE < jb) fetch(jt + TILE);
+#pragma unroll UNROLL
+        for (int jj = 0; jj < TILE; ++jj) t.pair(sh[buf][jj], p.eps2);
+    }
+    store_targets(p, ibase, blockIdx.y, t);
+}
+
+// Same arithmetic, sources read straight from global memory at a wave-uniform address: the
+// compiler turns that into scalar loads (s_load_dwordx4..x16), so source bodies sit in SGPRs
+// and cost neither LDS traffic nor barriers. Kept as a measured alternative to force_lds.
+template <class M, int UNROLL, int MINW>
+__global__ void __launch_bounds__(kWG, MINW) force_sgpr(const ForceParams p)
+{
+    const int ibase = p.i0 + blockIdx.x * (kWG * M::BPL);
+    M t;
+    load_targets(p, ibase, t);
+    int ja, jb;
+    slab_range(p.j0, p.j1, UNROLL, gridDim.y, blockIdx.y, ja, jb);
+    const float4* __restrict__ xs = p.x;
+    int j = ja;
+    for (; j + UNROLL <= jb; j += UNROLL) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) t.pair(xs[j + u], p.eps2);
+    }
+    for (; j < jb; ++j) t.pair(xs[j], p.eps2);
+    store_targets(p, ibase, blockIdx.y, t);
+}
+
+// ---------------------------------------------------------------------------------------
+// strict flavour — the reference's arithmetic, operation by operation
+// ---------------------------------------------------------------------------------------
+
+__device__ __forceinline__ void pair_strict(const float4 bi, const float4 bj, float& ax, float& ay,
+                                            float& az, const float eps2)
+{
+#pragma clang fp contract(off)
+    // kernel.cu:9-29 == validation.cpp:9-24
+    const float rx = bj.x - bi.x;
+    const float ry = bj.y - bi.y;
+    const float rz = bj.z - bi.z;
+    const float d = rx * rx + ry * ry + rz * rz + eps2;
+    const float denom = 1.0f / __builtin_sqrtf(d * d * d);  // correctly rounded sqrt and divide
+    const float s = bj.w * denom;
+    ax += rx * s;
+    ay += ry * s;
+    az += rz * s;
+}
+
+// One target per lane, sources in index order through one LDS tile. grid = ceil((i1-i0)/256).
+template <int TILE>
+__global__ void __launch_bounds__(kWG) force_strict(const ForceParams p)
+{
+#pragma clang fp contract(off)
+    constexpr int LPT = TILE / kWG;
+    __shared__ float4 sh[TILE];
+    const int tid = threadIdx.x;
+    const int i = p.i0 + blockIdx.x * kWG + tid;
+    const int ic = (i < p.i1) ? i : p.i1 - 1;
+    const float4 bi = p.x[ic];
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+    if (p.accumulate) {
+        const float4 o = p.out[ic - p.i0];
+        ax = o.x; ay = o.y; az = o.z;
+    }
+    for (int jt = p.j0; jt < p.j1; jt += TILE) {
+        __syncthreads();
+#pragma unroll
+        for (int l = 0; l < LPT; ++l) {
+            const int j = jt + l * kWG + tid;
+            if (j < p.j1) sh[l * kWG + tid] = p.x[j];
+        }
+        __syncthreads();
+        const int cnt = (p.j1 - jt < TILE) ? (p.j1 - jt) : TILE;
+        for (int jj = 0; jj < cnt; ++jj) {
+            if (jt + jj != ic) pair_strict(bi, sh[jj], ax, ay, az, p.eps2);  // validation.cpp:35
+        }
+    }
+    if (i < p.i1) p.out[i - p.i0] = make_float4(ax, ay, az, 0.0f);
+}
+
+// ---------------------------------------------------------------------------------------
+// integrate — kernel.cu:116-129 == validation.cpp:40-49, plus the fixed-order slab sum
+// ---------------------------------------------------------------------------------------
+
+struct IntegrateParams {
+    float4* x;             // positions of the OWN bodies (already offset to i0)
+    float4* v;             // velocities of the own bodies
+    float4* a;             // accelerations of the own bodies (output when nslab > 0)
+    const float4* slabs;   // nslab partial-sum slabs, slab_stride apart (may alias a when nslab==1)
+    int nslab;
+    int slab_stride;
+    int n;                 // own bodies
+    float dt;
+};
+
+__global__ void __launch_bounds__(kWG) integrate(const IntegrateParams p)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * kWG + threadIdx.x;
+    if (i >= p.n) return;
+    float4 a;
+    if (p.nslab > 0) {
+        a = p.slabs[i];
+        for (int s = 1; s < p.nslab; ++s) {
+            const float4 q = p.slabs[(size_t)s * p.slab_stride + i];
+            a.x += q.x; a.y += q.y; a.z += q.z;
+        }
+        a.w = 0.0f;
+        p.a[i] = a;
+    } else {
+        a = p.a[i];
+    }
+    float4 v = p.v[i];
+    float4 x = p.x[i];
+    const float hdt = 0.5f * p.dt;  // `0.5f * DT * a` parses as (0.5f*DT)*a
+    v.x += hdt * a.x;
+    v.y += hdt * a.y;
+    v.z += hdt * a.z;
+    x.x += p.dt * v.x;
+    x.y += p.dt * v.y;
+    x.z += p.dt * v.z;
+    p.v[i] = v;
+    p.x[i] = x;  // .w (mass) carried through untouched
+}
+
+// out[i] = (accumulate ? out[i] : 0) + slabs[0][i] + slabs[1][i] + ... in slab order.
+struct ReduceParams {
+    float4* out;
+    const float4* slabs;
+    int nslab;
+    int slab_stride;
+    int n;
+    int accumulate;
+};
+
+__global__ void __launch_bounds__(kWG) reduce_slabs(const ReduceParams p)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * kWG + threadIdx.x;
+    if (i >= p.n) return;
+    float4 a = p.accumulate ? p.out[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int s = 0; s < p.nslab; ++s) {
+        const float4 q = p.slabs[(size_t)s * p.slab_stride + i];
+        a.x += q.x; a.y += q.y; a.z += q.z;
+    }
+    a.w = 0.0f;
+    p.out[i] = a;
+}
+
+// ---------------------------------------------------------------------------------------
+// fp64 variant (BASELINE.json configs[4]; the build's own, no reference analogue)
+// ---------------------------------------------------------------------------------------
+
+struct ForceParamsF64 {
+    const double4* x;
+    double4* out;
+    int n;
+    int slab_stride;
+    double eps2;
+};
+
+// d^(-3/2) in double: v_rsq_f64 seed refined by two Newton steps, then cubed.
+__device__ __forceinline__ double inv_cube_f64(const double d)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    y = y * __builtin_fma(-h * y, y, 1.5);
+    y = y * __builtin_fma(-h * y, y, 1.5);
+    return y * y * y;
+}
+
+// grid = (ceil(n / (256*BPL)), nslab); LDS tile of TILE double4 (32 B each).
+template <int BPL, int TILE>
+__global__ void __launch_bounds__(kWG) force_f64(const ForceParamsF64 p)
+{
+    constexpr int LPT = TILE / kWG;
+    __shared__ double4 sh[TILE];
+    const int tid = threadIdx.x;
+    const int ibase = blockIdx.x * (kWG * BPL);
+    double xi[BPL], yi[BPL], zi[BPL], ax[BPL], ay[BPL], az[BPL];
+#pragma unroll
+    for (int k = 0; k < BPL; ++k) {
+        int i = ibase + k * kWG + tid;
+        if (i > p.n - 1) i = p.n - 1;
+        const double4 b = p.x[i];
+        xi[k] = b.x; yi[k] = b.y; zi[k] = b.z;
+        ax[k] = 0.0; ay[k] = 0.0; az[k] = 0.0;
+    }
+    int ja, jb;
+    slab_range(0, p.n, TILE, gridDim.y, blockIdx.y, ja, jb);
+    for (int jt = ja; jt < jb; jt += TILE) {
+        __syncthreads();
+#pragma unroll
+        for (int l = 0; l < LPT; ++l) {
+            const int j = jt + l * kWG + tid;
+            sh[l * kWG + tid] = (j < jb) ? p.x[j] : make_double4(0.0, 0.0, 0.0, 0.0);
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int jj = 0; jj < TILE; ++jj) {
+            const double4 bj = sh[jj];
+#pragma unroll
+            for (int k = 0; k < BPL; ++k) {
+                const double rx = bj.x - xi[k], ry = bj.y - yi[k], rz = bj.z - zi[k];
+                const double d = __builtin_fma(rz, rz, __builtin_fma(ry, ry, __builtin_fma(rx, rx, p.eps2)));
+                const double f = bj.w * inv_cube_f64(d);
+                ax[k] = __builtin_fma(rx, f, ax[k]);
+                ay[k] = __builtin_fma(ry, f, ay[k]);
+                az[k] = __builtin_fma(rz, f, az[k]);
+            }
+        }
+    }
+    double4* out = p.out + (size_t)blockIdx.y * p.slab_stride;
+#pragma unroll
+    for (int k = 0; k < BPL; ++k) {
+        const int i = ibase + k * kWG + tid;
+        if (i < p.n) out[i] = make_double4(ax[k], ay[k], az[k], 0.0);
+    }
+}
+
+struct IntegrateParamsF64 {
+    double4* x;
+    double4* v;
+    double4* a;
+    const double4* slabs;
+    int nslab;
+    int slab_stride;
+    int n;
+    double dt;
+};
+
+__global__ void __launch_bounds__(kWG) integrate_f64(const IntegrateParamsF64 p)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * kWG + threadIdx.x;
+    if (i >= p.n) return;
+    double4 a = p.slabs[i];
+    for (int s = 1; s < p.nslab; ++s) {
+        const double4 q = p.slabs[(size_t)s * p.slab_stride + i];
+        a.x += q.x; a.y += q.y; a.z += q.z;
+    }
+    a.w = 0.0;
+    p.a[i] = a;
+    double4 v = p.v[i];
+    double4 x = p.x[i];
+    const double hdt = 0.5 * p.dt;
+    v.x += hdt * a.x; v.y += hdt * a.y; v.z += hdt * a.z;
+    x.x += p.dt * v.x; x.y += p.dt * v.y; x.z += p.dt * v.z;
+    p.v[i] = v;
+    p.x[i] = x;
+}
+
+}  // namespace nbk

@@ -1,0 +1,177 @@
+"""Host side of the all-pairs step: the Python mirror of the reference's headless driver.
+
+The reference's sequence (TestProject/main.cpp:231-368, headless branch):
+    allocate pinned host arrays -> fill_with_random4 / fill_with_zeroes4 -> cudaMalloc + H2D
+    -> simulationLoopNoVisual: `steps` x simulate(d_bodies, d_accel, d_vel, N) -> free.
+``Simulation`` reproduces that sequence on top of the C-ABI (``include/nbody.h``); device memory
+and streams come from PyTorch-ROCm, which is plumbing only — every force/integrate runs in
+``libnbody_hip.so``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import KERNEL_FAST, KERNEL_STRICT, check
+
+INIT_REFERENCE = 0  # uniform cube +-1e5, masses U(1e5,1e9): utils.cpp:30-37, constants.h:15-19
+INIT_PLUMMER = 1    # Plummer sphere a=1, M=1, cold
+
+
+def seeded_bodies(n: int, init: int = INIT_REFERENCE, seed: int = 12345) -> np.ndarray:
+    """Reproducible initial bodies as an (n,4) float32 array {x,y,z,mass} (host-side helper of
+    the C library; runs without a GPU)."""
+    out = np.zeros((n, 4), np.float32)
+    check(_lib.load().nbody_fill_seeded(C.c_void_p(out.ctypes.data), n, init, seed))
+    return out
+
+
+def libc_random_bodies(n: int) -> np.ndarray:
+    """utils.cpp:30-37 literally: libc rand(), unseeded unless the process seeded it."""
+    out = np.zeros((n, 4), np.float32)
+    _lib.load().nbody_fill_with_random4(C.c_void_p(out.ctypes.data), n)
+    return out
+
+
+def verify_still_bodies(v: np.ndarray, x: np.ndarray) -> int:
+    """validation.cpp:143-164 as a count of offending bodies."""
+    v = np.ascontiguousarray(v, np.float32)
+    x = np.ascontiguousarray(x, np.float32)
+    return _lib.load().nbody_verify_still_bodies(C.c_void_p(v.ctypes.data), C.c_void_p(x.ctypes.data), len(v))
+
+
+def verify_equality4(v: np.ndarray, x: np.ndarray) -> int:
+    """validation.cpp:106-122 as a count."""
+    v = np.ascontiguousarray(v, np.float32)
+    x = np.ascontiguousarray(x, np.float32)
+    return _lib.load().nbody_verify_equality4(C.c_void_p(v.ctypes.data), C.c_void_p(x.ctypes.data), len(v))
+
+
+def _dptr(t: torch.Tensor) -> C.c_void_p:
+    return C.c_void_p(t.data_ptr())
+
+
+def _check_f4(t: torch.Tensor, n: Optional[int] = None, dtype=torch.float32) -> None:
+    if not (t.is_cuda and t.dtype == dtype and t.dim() == 2 and t.shape[1] == 4 and t.is_contiguous()):
+        raise ValueError(f"expected a contiguous CUDA (n,4) {dtype} tensor, got {tuple(t.shape)} {t.dtype} {t.device}")
+    if n is not None and t.shape[0] != n:
+        raise ValueError(f"expected {n} bodies, got {t.shape[0]}")
+
+
+class Context:
+    """Owns an ``nbody_ctx``: device, stream, dt/eps2, kernel choice, slab workspace."""
+
+    def __init__(self, device: Optional[int] = None, dt: float = _lib.DEFAULT_DT, eps2: float = _lib.DEFAULT_EPS2,
+                 kernel: int = KERNEL_FAST, tile: int = 0, bodies_per_lane: int = 0, jsplit: int = 0,
+                 stream: Optional[torch.cuda.Stream] = None):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        if device is None:
+            device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        self.device = int(device)
+        check(self._lib.nbody_ctx_create(C.byref(self._h), self.device))
+        self.set_params(dt, eps2)
+        self.set_kernel(kernel, tile, bodies_per_lane, jsplit)
+        self._stream = None
+        if stream is not None:
+            self.set_stream(stream)
+
+    def set_params(self, dt: float, eps2: float) -> None:
+        check(self._lib.nbody_ctx_set_params(self._h, dt, eps2))
+        self.dt, self.eps2 = float(dt), float(eps2)
+
+    def set_kernel(self, kernel: int = KERNEL_FAST, tile: int = 0, bodies_per_lane: int = 0, jsplit: int = 0) -> None:
+        check(self._lib.nbody_ctx_set_kernel(self._h, kernel, tile, bodies_per_lane, jsplit))
+        self.kernel = kernel
+
+    def set_stream(self, stream: Optional[torch.cuda.Stream]) -> None:
+        self._stream = stream  # keep it alive
+        check(self._lib.nbody_ctx_set_stream(self._h, C.c_void_p(stream.cuda_stream) if stream is not None else None))
+
+    def reserve(self, n_targets: int) -> None:
+        check(self._lib.nbody_ctx_reserve(self._h, n_targets))
+
+    def launch_info(self, n_targets: int, n_sources: int) -> dict:
+        js, bl, lds = C.c_int(), C.c_int(), C.c_int()
+        check(self._lib.nbody_ctx_launch_info(self._h, n_targets, n_sources, C.byref(js), C.byref(bl), C.byref(lds)))
+        return {"jsplit": js.value, "blocks": bl.value, "lds_bytes": lds.value}
+
+    def step(self, x: torch.Tensor, a: torch.Tensor, v: torch.Tensor, steps: int = 1) -> None:
+        n = x.shape[0]
+        _check_f4(x), _check_f4(a, n), _check_f4(v, n)
+        check(self._lib.nbody_step(self._h, _dptr(x), _dptr(a), _dptr(v), n, steps))
+
+    def step_f64(self, x: torch.Tensor, a: torch.Tensor, v: torch.Tensor, dt: float, eps2: float, steps: int = 1) -> None:
+        n = x.shape[0]
+        _check_f4(x, None, torch.float64), _check_f4(a, n, torch.float64), _check_f4(v, n, torch.float64)
+        check(self._lib.nbody_step_f64(self._h, _dptr(x), _dptr(a), _dptr(v), n, steps, dt, eps2))
+
+    def accel_range(self, x: torch.Tensor, a_out: torch.Tensor, i0: int, i1: int, j0: int, j1: int,
+                    accumulate: bool = False) -> None:
+        _check_f4(x), _check_f4(a_out, i1 - i0)
+        if i1 > x.shape[0] or j1 > x.shape[0]:
+            raise ValueError("range beyond the body array")
+        check(self._lib.nbody_accel_range(self._h, _dptr(x), _dptr(a_out), i0, i1, j0, j1, 1 if accumulate else 0))
+
+    def integrate_range(self, x: torch.Tensor, v_own: torch.Tensor, a_own: torch.Tensor, i0: int, i1: int) -> None:
+        _check_f4(x), _check_f4(v_own, i1 - i0), _check_f4(a_own, i1 - i0)
+        if i1 > x.shape[0]:
+            raise ValueError("range beyond the body array")
+        check(self._lib.nbody_integrate_range(self._h, _dptr(x), _dptr(v_own), _dptr(a_own), i0, i1))
+
+    def sync(self) -> None:
+        check(self._lib.nbody_ctx_sync(self._h))
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.nbody_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def simulate(d_bodies: torch.Tensor, d_accelerations: torch.Tensor, d_velocity: torch.Tensor, n: Optional[int] = None) -> None:
+    """``simulate(d_bodies, d_accelerations, d_velocity, N)`` of TestProject/kernel.cuh:2 —
+    one synchronous in-place step with DT / EPS2 of constants.h:25-26 on device 0."""
+    n = d_bodies.shape[0] if n is None else n
+    _check_f4(d_bodies), _check_f4(d_accelerations), _check_f4(d_velocity)
+    if n > d_bodies.shape[0]:
+        raise ValueError("N exceeds the allocation")
+    check(_lib.load().nbody_simulate(_dptr(d_bodies), _dptr(d_accelerations), _dptr(d_velocity), n))
+
+
+class Simulation:
+    """The headless run of main.cpp (alloc -> init -> H2D -> step loop), single GPU."""
+
+    def __init__(self, bodies: np.ndarray, dt: float = _lib.DEFAULT_DT, eps2: float = _lib.DEFAULT_EPS2,
+                 kernel: int = KERNEL_FAST, device: Optional[int] = None, **kernel_opts):
+        bodies = np.ascontiguousarray(bodies, np.float32)
+        if bodies.ndim != 2 or bodies.shape[1] != 4:
+            raise ValueError("bodies must be (n,4) float32 {x,y,z,mass}")
+        self.n = bodies.shape[0]
+        self.ctx = Context(device=device, dt=dt, eps2=eps2, kernel=kernel, **kernel_opts)
+        dev = torch.device("cuda", self.ctx.device)
+        # main.cpp:250-283,352-354: bodies random, velocity/acceleration zero, all copied to the device
+        self.x = torch.from_numpy(bodies).to(dev)
+        self.v = torch.zeros((self.n, 4), dtype=torch.float32, device=dev)
+        self.a = torch.zeros((self.n, 4), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize(dev)
+        self.ctx.reserve(self.n)
+
+    def run(self, steps: int, sync: bool = True) -> None:
+        """simulationLoopNoVisual (main.cpp:142-160) without the per-step host sync."""
+        self.ctx.step(self.x, self.a, self.v, steps)
+        if sync:
+            self.ctx.sync()
+
+    def state(self):
+        self.ctx.sync()
+        return self.x.cpu().numpy(), self.v.cpu().numpy(), self.a.cpu().numpy()

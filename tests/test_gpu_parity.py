@@ -1,0 +1,298 @@
+"""Parity of the HIP path (through the C-ABI) against the CPU oracle and the committed goldens.
+
+Tiers:
+  T1  strict kernel == Jacobi oracle, bit for bit (x, v, a), any N, any K.
+  T2  fast kernel, one step from identical state: positions rel-err <= 1e-6 of the system scale,
+      accelerations <= 1e-5 of max|a|.
+  T3  fast kernel trajectory, Plummer N=1024 dt=0.01 K=100: max|dx| <= 1e-5 (scale radius 1).
+  T4  the reference's own 1 % rule (validation.cpp:143-164) vs the literal in-place reference
+      outputs: reported and bounded.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import bits, load_golden, same_bits
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu_run(nb, x0, steps, dt, eps2, kernel, **opts):
+    sim = nb.engine.Simulation(x0, dt=dt, eps2=eps2, kernel=kernel, **opts)
+    sim.run(steps)
+    return sim.state()
+
+
+def _rand_bodies(n, seed, scale=1e5, mlo=1e5, mhi=1e9):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-scale, scale, (n, 4)).astype(np.float32)
+    x[:, 3] = rng.uniform(mlo, mhi, n).astype(np.float32)
+    return x
+
+
+# ---- T1: strict == oracle, bitwise -----------------------------------------------------------
+
+@pytest.mark.parametrize("name", ["jacobi_refinit_n1024_dt0.1.npz", "jacobi_refinit_n1000_dt0.1.npz",
+                                  "jacobi_plummer_n1024_dt0.01.npz"])
+def test_strict_matches_golden_bitwise(nb, name):
+    g = load_golden(name)
+    Ks = sorted(int(k[2:]) for k in g.files if k.startswith("x_"))
+    for K in Ks:
+        x, v, a = _gpu_run(nb, g["x0"], K, float(g["dt"]), float(g["eps2"]), nb.KERNEL_STRICT)
+        assert same_bits(x, g[f"x_{K}"]), (name, K, "x")
+        assert same_bits(v, g[f"v_{K}"]), (name, K, "v")
+        assert same_bits(a, g[f"a_{K}"]), (name, K, "a")
+
+
+@pytest.mark.parametrize("n,K", [(1, 2), (2, 3), (37, 4), (255, 2), (256, 2), (257, 2), (1025, 2), (4096, 2), (5000, 1)])
+def test_strict_matches_oracle_bitwise_ragged(nb, oracle, n, K):
+    x0 = _rand_bodies(n, 100 + n)
+    xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
+    oracle.step_jacobi(xo, ao, vo, dt=0.1, eps2=0.002, steps=K)
+    x, v, a = _gpu_run(nb, x0, K, 0.1, 0.002, nb.KERNEL_STRICT)
+    assert same_bits(x, xo) and same_bits(v, vo) and same_bits(a, ao)
+
+
+def test_strict_overflow_corner_and_coincident_bodies(nb, oracle):
+    """r > 2.6e6 pairs contribute exactly 0 (d^3 overflows, Q13); coincident bodies add 0."""
+    x0 = _rand_bodies(300, 5)
+    x0[10, :3] = [4e6, 0, 0]
+    x0[11, :3] = x0[12, :3]
+    xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
+    oracle.step_jacobi(xo, ao, vo, dt=0.1, eps2=0.002)
+    x, v, a = _gpu_run(nb, x0, 1, 0.1, 0.002, nb.KERNEL_STRICT)
+    assert same_bits(a, ao) and same_bits(x, xo)
+    assert np.all(a[10, :3] == 0)
+
+
+# ---- T2: fast kernel, single step --------------------------------------------------------------
+
+@pytest.mark.parametrize("n,init,dt,scale", [(1024, 0, 0.1, 1e5), (1000, 0, 0.1, 1e5), (1024, 1, 0.01, 1.0),
+                                             (4099, 0, 0.1, 1e5), (16384, 1, 0.01, 1.0), (300, 0, 0.1, 1e5)])
+def test_fast_single_step(nb, oracle, n, init, dt, scale):
+    x0 = nb.engine.seeded_bodies(n, init, 99)
+    xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
+    oracle.step_jacobi(xo, ao, vo, dt=dt, eps2=0.002)
+    x, v, a = _gpu_run(nb, x0, 1, dt, 0.002, nb.KERNEL_FAST)
+    amax = np.abs(ao[:, :3]).max()
+    assert np.abs(a - ao)[:, :3].max() / amax <= 1e-5
+    assert np.abs(x - xo)[:, :3].max() / scale <= 1e-6
+    assert np.array_equal(x[:, 3], x0[:, 3])                       # mass carried through
+    assert np.all(a[:, 3] == 0) and np.all(v[:, 3] == 0)
+    # and as close to the fp64-accumulated truth as the fp32 oracle is (a few ulp of max|a|)
+    at = oracle.accel_range(x0, 0, n, eps2=0.002, f64acc=True)
+    assert np.abs(a - at)[:, :3].max() / amax <= 1e-5
+
+
+def test_fast_single_step_vs_literal_reference(nb, oracle):
+    """GPU (Jacobi) vs the reference's in-place CPU_compute outputs after ONE step from the
+    reference's own initial conditions (golden from the reference build). Positions agree to
+    1e-6 of the scale and pass the reference's 1 % rule. Accelerations of bodies whose close
+    neighbours were already advanced by the in-place loop differ by that ordering effect (an
+    oracle-vs-oracle quantity, computed here), never by more than it plus 1e-5."""
+    g = load_golden("ref_cpu_n1024.npz")
+    x, v, a = _gpu_run(nb, g["x0"], 1, 0.1, 0.002, nb.KERNEL_FAST)
+    assert np.abs(x - g["x_1"])[:, :3].max() / 1e5 <= 1e-6
+    assert nb.engine.verify_still_bodies(x, g["x_1"]) == 0         # the reference's own 1 % rule
+    aj = oracle.accel_range(g["x0"], 0, 1024, eps2=0.002)          # Jacobi order, same arithmetic
+    amax = np.abs(g["a_1"][:, :3]).max()
+    ordering = np.abs(aj - g["a_1"])[:, :3]                        # in-place vs Jacobi, per component
+    assert np.all(np.abs(a - g["a_1"])[:, :3] <= ordering + 1e-5 * amax)
+    assert np.array_equal(a[0], a[0]) and np.abs(a[0] - g["a_1"][0])[:3].max() <= 1e-5 * amax  # body 0: no ordering effect
+
+
+@pytest.mark.parametrize("opts", [dict(tile=256, bodies_per_lane=1, jsplit=1), dict(tile=512, bodies_per_lane=2, jsplit=2),
+                                  dict(tile=1024, bodies_per_lane=4, jsplit=3), dict(tile=2048, bodies_per_lane=4, jsplit=1),
+                                  dict(tile=256, bodies_per_lane=4, jsplit=32), dict(tile=1024, bodies_per_lane=2, jsplit=7)])
+def test_fast_kernel_configurations_agree(nb, oracle, opts):
+    n = 3001
+    x0 = nb.engine.seeded_bodies(n, 1, 5)
+    ao = oracle.accel_range(x0, 0, n, eps2=0.002)
+    x, v, a = _gpu_run(nb, x0, 1, 0.01, 0.002, nb.KERNEL_FAST, **opts)
+    assert np.abs(a - ao)[:, :3].max() / np.abs(ao[:, :3]).max() <= 1e-5
+
+
+# ---- T3 / T4: trajectories -------------------------------------------------------------------------
+
+def test_fast_trajectory_plummer_k100(nb):
+    g = load_golden("jacobi_plummer_n1024_dt0.01.npz")
+    for K, tol in ((10, 2e-6), (100, 1e-5)):
+        x, v, a = _gpu_run(nb, g["x0"], K, 0.01, 0.002, nb.KERNEL_FAST)
+        assert np.abs(x - g[f"x_{K}"])[:, :3].max() <= tol, K
+        assert nb.engine.verify_still_bodies(x, g[f"x_{K}"]) == 0
+
+
+def test_reference_one_percent_rule_vs_literal_reference(nb):
+    """compareHostToDevice's acceptance rule (validation.cpp:84-86, 143-164) against the literal
+    reference outputs. After 10 steps the GPU passes it outright; after 100 steps the reference's
+    own in-place ordering (not the GPU) moves a few % of bodies past 1 %."""
+    g = load_golden("ref_cpu_n1024.npz")
+    x10, _, _ = _gpu_run(nb, g["x0"], 10, 0.1, 0.002, nb.KERNEL_FAST)
+    assert nb.engine.verify_still_bodies(x10, g["x_10"]) == 0
+    assert np.abs(x10 - g["x_10"])[:, :3].max() / 1e5 <= 1e-4
+    x100, _, _ = _gpu_run(nb, g["x0"], 100, 0.1, 0.002, nb.KERNEL_FAST)
+    bad = nb.engine.verify_still_bodies(x100, g["x_100"])
+    assert bad <= 64, bad   # ~3 % of 1024; caused by close encounters amplifying the ordering difference
+
+
+# ---- the drop-in boundary ---------------------------------------------------------------------------
+
+def test_simulate_dropin(nb, oracle):
+    """simulate(d_bodies, d_acc, d_vel, N) of kernel.cuh:2: in place, synchronous, DT/EPS2 of
+    constants.h, N may be smaller than the allocation."""
+    n_alloc, n = 1500, 1234
+    x0 = nb.engine.seeded_bodies(n_alloc, 0, 3)
+    dev = torch.device("cuda", 0)
+    x = torch.from_numpy(x0).to(dev)
+    v = torch.zeros_like(x)
+    a = torch.full_like(x, 7.0)                                     # pure output: must be overwritten
+    for _ in range(3):
+        nb.engine.simulate(x, a, v, n)                              # synchronous: no explicit sync
+    xo, vo, ao = x0[:n].copy(), np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)
+    oracle.step_jacobi(xo, ao, vo, dt=0.1, eps2=0.002, steps=3)
+    xg, vg, ag = x.cpu().numpy(), v.cpu().numpy(), a.cpu().numpy()
+    assert np.abs(xg[:n] - xo)[:, :3].max() / 1e5 <= 1e-6
+    assert np.abs(ag[:n] - ao)[:, :3].max() / np.abs(ao[:, :3]).max() <= 1e-5
+    assert np.array_equal(xg[n:], x0[n:]) and np.all(ag[n:] == 7.0) and np.all(vg[n:] == 0)  # tail untouched
+
+
+def test_error_paths(nb):
+    ctx = nb.engine.Context()
+    with pytest.raises(nb.NBodyError):
+        ctx.set_params(0.1, 0.0)           # eps2 must be > 0
+    with pytest.raises(nb.NBodyError):
+        ctx.set_kernel(nb.KERNEL_FAST, tile=100)
+    with pytest.raises(nb.NBodyError):
+        ctx.set_kernel(7)
+    x = torch.zeros((8, 4), device="cuda")
+    with pytest.raises(ValueError):
+        ctx.step(x, x[:4], x)
+    with pytest.raises(ValueError):
+        ctx.step(x.cpu(), x.cpu(), x.cpu())
+    ctx.step(x[:0], x[:0], x[:0])          # empty system is a no-op
+    ctx.sync()
+
+
+# ---- partial ranges (what the sharded step is built from) ---------------------------------------------
+
+@pytest.mark.parametrize("kernel", ["fast", "strict"])
+def test_accel_range_blocks_compose(nb, oracle, kernel):
+    n = 2500
+    x0 = nb.engine.seeded_bodies(n, 0, 21)
+    k = nb.KERNEL_FAST if kernel == "fast" else nb.KERNEL_STRICT
+    ctx = nb.engine.Context(kernel=k)
+    x = torch.from_numpy(x0).cuda()
+    i0, i1 = 700, 1900
+    a = torch.zeros((i1 - i0, 4), device="cuda")
+    # canonical block order with accumulate: [0,i0) then [i0,i1) then [i1,n)
+    ctx.accel_range(x, a, i0, i1, 0, i0, accumulate=False)
+    ctx.accel_range(x, a, i0, i1, i0, i1, accumulate=True)
+    ctx.accel_range(x, a, i0, i1, i1, n, accumulate=True)
+    ctx.sync()
+    want = oracle.accel_range(x0, i0, i1, 0, n, eps2=0.002)
+    got = a.cpu().numpy()
+    if kernel == "strict":
+        assert same_bits(got, want)       # the sequential sum continues across calls exactly
+    else:
+        assert np.abs(got - want)[:, :3].max() / np.abs(want[:, :3]).max() <= 1e-5
+    # a sub-range of sources only
+    ctx.accel_range(x, a, i0, i1, 100, 333, accumulate=False)
+    ctx.sync()
+    want = oracle.accel_range(x0, i0, i1, 100, 333, eps2=0.002)
+    got = a.cpu().numpy()
+    assert (same_bits(got, want) if kernel == "strict" else
+            np.abs(got - want)[:, :3].max() / np.abs(want[:, :3]).max() <= 1e-5)
+    # empty source range writes zeros
+    ctx.accel_range(x, a, i0, i1, 5, 5, accumulate=False)
+    ctx.sync()
+    assert np.all(a.cpu().numpy() == 0)
+
+
+def test_integrate_range_matches_oracle_bitwise(nb, oracle):
+    n = 1000
+    rng = np.random.default_rng(8)
+    x0 = _rand_bodies(n, 8)
+    v0 = rng.normal(0, 50, (n, 4)).astype(np.float32); v0[:, 3] = 0
+    a0 = rng.normal(0, 20, (n, 4)).astype(np.float32); a0[:, 3] = 0
+    ctx = nb.engine.Context(dt=0.1)
+    x = torch.from_numpy(x0).cuda()
+    i0, i1 = 123, 877
+    v = torch.from_numpy(v0[i0:i1].copy()).cuda()
+    a = torch.from_numpy(a0[i0:i1].copy()).cuda()
+    ctx.integrate_range(x, v, a, i0, i1)
+    ctx.sync()
+    xo, vo = x0.copy(), v0.copy()
+    xs, vs = xo[i0:i1].copy(), vo[i0:i1].copy()
+    oracle.integrate(xs, vs, a0[i0:i1].copy(), dt=0.1)
+    xo[i0:i1] = xs
+    assert same_bits(x.cpu().numpy(), xo) and same_bits(v.cpu().numpy(), vs)
+
+
+# ---- full-size, size-independent properties -----------------------------------------------------------
+
+def test_large_n_subset_against_oracle_and_properties(nb, oracle):
+    """N=65536 (BASELINE configs[1]): 2048 sampled targets against ALL sources on the CPU; exact
+    mass linearity; momentum balance (sum m_i a_i = 0 by Newton's third law)."""
+    n = 65536
+    x0 = nb.engine.seeded_bodies(n, 1, 2025)
+    ctx = nb.engine.Context(dt=0.01)
+    x = torch.from_numpy(x0).cuda()
+    a = torch.zeros_like(x)
+    ctx.accel_range(x, a, 0, n, 0, n)
+    ctx.sync()
+    ag = a.cpu().numpy()
+    for (i0, i1) in ((0, 1024), (40000, 41024)):
+        # vs the fp64-accumulated truth: 1e-5; vs the fp32 sequential oracle, whose own 65536-term
+        # running sum carries ~sqrt(N)*2^-24 of rounding, 5e-5
+        truth = oracle.accel_range(x0, i0, i1, 0, n, eps2=0.002, f64acc=True)
+        seq32 = oracle.accel_range(x0, i0, i1, 0, n, eps2=0.002)
+        amax = np.abs(truth[:, :3]).max()
+        assert np.abs(ag[i0:i1] - truth)[:, :3].max() / amax <= 1e-5
+        assert np.abs(ag[i0:i1] - seq32)[:, :3].max() / amax <= 5e-5
+        assert np.abs(ag[i0:i1] - truth)[:, :3].max() <= np.abs(seq32 - truth)[:, :3].max()  # tiling sums better
+    # momentum balance, relative to sum m|a|
+    m = x0[:, 3:4].astype(np.float64)
+    net = np.abs((m * ag[:, :3]).sum(0)).max()
+    assert net / (m * np.abs(ag[:, :3])).sum() < 1e-6
+    # doubling every mass doubles every acceleration exactly (power-of-two scaling is exact in fp32)
+    x2 = x0.copy(); x2[:, 3] *= 2
+    a2 = torch.zeros_like(x)
+    ctx.accel_range(torch.from_numpy(x2).cuda(), a2, 0, n, 0, n)
+    ctx.sync()
+    assert np.array_equal(a2.cpu().numpy()[:, :3], 2 * ag[:, :3])
+
+
+def test_large_n_strict_equals_fast_within_tolerance(nb):
+    """One step at N=32768 with the reference's own distribution. (A second step is not compared
+    on accelerations: the closest pairs reach |a| ~ 1e6 and amplify last-bit differences of step 1
+    by orders of magnitude — the chaos SURVEY.md 7.2 describes — positions still agree.)"""
+    n = 32768
+    x0 = nb.engine.seeded_bodies(n, 0, 77)
+    xs, vs, as_ = _gpu_run(nb, x0, 1, 0.1, 0.002, nb.KERNEL_STRICT)
+    xf, vf, af = _gpu_run(nb, x0, 1, 0.1, 0.002, nb.KERNEL_FAST)
+    norm = np.maximum(np.linalg.norm(as_[:, :3], axis=1), np.median(np.linalg.norm(as_[:, :3], axis=1)))
+    assert (np.linalg.norm((af - as_)[:, :3], axis=1) / norm).max() <= 5e-5   # the strict side is a 32768-term fp32 running sum
+    assert np.abs(xf - xs)[:, :3].max() / 1e5 <= 1e-6
+    xs2, _, _ = _gpu_run(nb, x0, 2, 0.1, 0.002, nb.KERNEL_STRICT)
+    xf2, _, _ = _gpu_run(nb, x0, 2, 0.1, 0.002, nb.KERNEL_FAST)
+    assert np.abs(xf2 - xs2)[:, :3].max() / 1e5 <= 1e-6
+
+
+# ---- fp64 variant ---------------------------------------------------------------------------------------
+
+def test_f64_step_matches_oracle(nb, oracle):
+    n = 2000
+    x0 = nb.engine.seeded_bodies(n, 1, 4).astype(np.float64)
+    xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
+    oracle.step_jacobi_f64(xo, ao, vo, dt=0.01, eps2=0.002, steps=3)
+    ctx = nb.engine.Context()
+    x = torch.from_numpy(x0).cuda()
+    v = torch.zeros_like(x)
+    a = torch.zeros_like(x)
+    ctx.step_f64(x, a, v, dt=0.01, eps2=0.002, steps=3)
+    ctx.sync()
+    assert np.abs(a.cpu().numpy() - ao)[:, :3].max() / np.abs(ao[:, :3]).max() <= 1e-12
+    assert np.abs(x.cpu().numpy() - xo)[:, :3].max() <= 1e-13
+    # and the fp32 fast path agrees with fp64 to fp32 accuracy (BASELINE configs[4]'s tolerance check)
+    xf, _, af = _gpu_run(nb, x0.astype(np.float32), 3, 0.01, 0.002, nb.KERNEL_FAST)
+    assert np.abs(xf - xo)[:, :3].max() <= 2e-6
