@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py — body-pair interactions/s of the all-pairs step on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n BODIES]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over all bodies: the O(N^2) force accumulation followed by
+the half-kick/drift integrate (TestProject/kernel.cu:80-130 in the reference).
+
+Workload (BASELINE.json): N = 262144 bodies, fp32, 1 GPU (configs[2], the size the metric is quoted
+on). With G > 1 ranks the bodies are block-partitioned and positions all-gathered once per step
+(RCCL); the run is WEAK-scaled: N(G) = 262144 * sqrt(G) rounded to a multiple of 1024*G, so every
+GPU evaluates the same 6.87e10 pairs per step. `--n` overrides (e.g. --n 1048576 for configs[3]).
+
+Rank 0 prints ONE JSON line. `value` = N^2 * steps / wall time of the timed region (max over
+ranks), inputs resident in HBM before the region starts. `roofline` is the force kernel's
+algorithmic FLOP rate (20 FLOP/pair) over its own HIP-event time on its launch
+stream, against the 157.3 TFLOP/s fp32 vector peak; `cpu_baseline` times the reference's own CPU
+path (oracle/_ref, kind "reference") or the checker's restatement (kind "port") on a bounded
+sample on the host cores — a reported baseline, not the product.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_PAIR = 20.0            # the agreed algorithmic count
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
+BASE_N = 262144
+
+
+def weak_n(gpus: int) -> int:
+    if gpus == 1:
+        return BASE_N
+    q = 1024 * gpus
+    return int(round(BASE_N * math.sqrt(gpus) / q)) * q
+
+
+def cpu_baseline(seconds_budget: float = 12.0):
+    """Times the reference's CPU step (serial, as the reference builds it) on a bounded sample."""
+    import numpy as np
+    from oracle import oracle as O   # checker / baseline only — never the measured product
+    import nbody_amd
+    n = 16384
+    x0 = nbody_amd.engine.seeded_bodies(n, 0, 12345)
+    out = {}
+    if O.have_ref():
+        fn, kind = O.ref_step, "reference"
+    else:
+        fn, kind = (lambda x, a, v, steps=1: O.step_inplace(x, a, v, steps=steps)), "port"
+    x, v, a = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
+    fn(x, a, v, steps=1)            # warm caches
+    t0 = time.perf_counter()
+    done = 0
+    while done < 64:
+        fn(x, a, v, steps=1)
+        done += 1
+        if time.perf_counter() - t0 > seconds_budget:
+            break
+    dt = time.perf_counter() - t0
+    out.update({"value": n * (n - 1) * done / dt, "unit": "pairs/s", "cores": 1, "kind": kind,
+                "sample": f"{done} serial in-place steps of validation.cpp:28-52 at N={n} (reference init, DT=0.1, EPS2=0.002), {dt:.1f} s"})
+    # the best honest CPU line: our Jacobi restatement, SIMD over targets, OpenMP over all cores
+    thr = O.max_threads()
+    O.set_threads(thr)
+    O.accel_range(x0, 0, n)          # spin up the thread pool
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 200:
+        O.accel_range(x0, 0, n)
+        reps += 1
+        if time.perf_counter() - t0 > seconds_budget / 3:
+            break
+    dt2 = time.perf_counter() - t0
+    out.update({"port_all_cores_value": n * (n - 1) * reps / dt2, "port_all_cores": thr,
+                "host_cpus": os.cpu_count()})
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=0, help="bodies (default: weak-scaled from 262144)")
+    ap.add_argument("--dt", type=float, default=0.01)
+    ap.add_argument("--eps2", type=float, default=0.002)
+    ap.add_argument("--init", type=int, default=1, help="0 reference cube, 1 Plummer")
+    ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--bpl", type=int, default=0)
+    ap.add_argument("--jsplit", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import nbody_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("for --gpus > 1 launch through torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = args.n or weak_n(world)
+    x0 = nbody_amd.engine.seeded_bodies(n, args.init, 12345)
+    kopts = dict(tile=args.tile, bodies_per_lane=args.bpl, jsplit=args.jsplit)
+
+    if world == 1:
+        sim = nbody_amd.engine.Simulation(x0, dt=args.dt, eps2=args.eps2, device=local_rank, **kopts)
+        ctx = sim.ctx
+        run = lambda k: sim.run(k, sync=False)
+        sync = ctx.sync
+        info = ctx.launch_info(n, n)
+        pairs_per_launch = float(n) * n
+    else:
+        sim = nbody_amd.sharded.ShardedSimulation(x0, dt=args.dt, eps2=args.eps2, **kopts)
+        ctx = sim.backend.ctx
+        run = sim.step
+        sync = sim.sync
+        info = ctx.launch_info(sim.shard, sim.shard)
+        pairs_per_launch = None  # several launches of different sizes per step: use the step total
+
+    def barrier():
+        sync()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+
+    run(args.warmup)
+    barrier()
+    ctx.timing(True)
+    t0 = time.perf_counter()
+    run(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    force_ms, launches = ctx.timing_read()
+    ctx.timing(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    pairs_total = float(n) * n * args.steps
+    value = pairs_total / elapsed
+    # roofline of the dominant kernel (force accumulation), from its own event time on this rank
+    rank_pairs = float(sim.shard) * sim.n_pad * args.steps if world > 1 else pairs_total
+    kernel_s = force_ms * 1e-3
+    achieved = FLOP_PER_PAIR * rank_pairs / kernel_s / 1e12 if kernel_s > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("force_kernel_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    line = {
+        "metric": "body_pair_interactions_per_s",
+        "value": value,
+        "unit": "pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"all-pairs gravity step, N={n} bodies, fp32, {'Plummer' if args.init == 1 else 'reference-cube'} init seed 12345, "
+                        f"dt={args.dt}, eps2={args.eps2}",
+            "n_bodies": n,
+            "pairs_per_step": float(n) * n,
+            "partition": "single GPU" if world == 1 else f"{world} contiguous blocks of {sim.shard} bodies, RCCL all-gather of positions per step",
+            "kernel": nbody_amd.load().nbody_version().decode(),
+            "launch": info,
+            "gflops_at_20_flop_per_pair": value * FLOP_PER_PAIR / 1e9,
+        },
+        "roofline": {
+            "bound": "valu",
+            "achieved": achieved,
+            "peak": FP32_VECTOR_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved / FP32_VECTOR_PEAK_TFLOPS,
+            "traffic": traffic,
+            "kernel": "nbk::force_lds (fp32 packed)",
+            "kernel_ms_avg": force_ms / max(launches, 1),
+            "kernel_launches": launches,
+            "flop_per_pair": FLOP_PER_PAIR,
+            "note": "fp32 vector-ALU bound (no MFMA, HBM traffic is O(N) per step); peak = 157.3 TFLOP/s fp32 vector = fp32 MFMA peak",
+        },
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                line["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -153,6 +153,14 @@ int nbody_fill_seeded(nbody_float4* h_bodies, int n, int init, unsigned long lon
 int nbody_verify_still_bodies(const nbody_float4* h_v, const nbody_float4* h_x, int n);
 int nbody_verify_equality4(const nbody_float4* h_v, const nbody_float4* h_x, int n);
 
+/* ---- measurement ------------------------------------------------------------------------- */
+/* With timing on, every force-kernel launch made through this context is bracketed by a pair of
+ * hipEvents on the launch stream. nbody_ctx_timing_read() synchronises the stream, returns the
+ * summed force-kernel time (ms) and the number of launches since the last read, and resets the
+ * counters. (bench.py's roofline figure; costs two event records per launch.) */
+int nbody_ctx_timing(nbody_ctx* ctx, int enable);
+int nbody_ctx_timing_read(nbody_ctx* ctx, double* force_ms, int* launches);
+
 /* ---- diagnostics ------------------------------------------------------------------------- */
 const char* nbody_last_error(void);
 /* e.g. "nbody_hip 0.1 gfx950 fast=lds-packed bpl4 tile1024" */

@@ -49,6 +49,8 @@ _SIGNATURES = {
     "nbody_accel_range": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "nbody_integrate_range": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int]),
     "nbody_ctx_sync": (C.c_int, [_p]),
+    "nbody_ctx_timing": (C.c_int, [_p, C.c_int]),
+    "nbody_ctx_timing_read": (C.c_int, [_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "nbody_step_f64": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_double, C.c_double]),
     "nbody_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "nbody_malloc_device": (C.c_int, [C.POINTER(_p), C.c_size_t]),

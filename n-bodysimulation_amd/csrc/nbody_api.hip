@@ -14,6 +14,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <vector>
 
 #include "nbody_kernels.hip.h"
 
@@ -58,6 +59,9 @@ struct nbody_ctx {
     int num_cu = 256;
     void* slabs = nullptr;     // workspace: jsplit slabs of n_targets float4 (or double4)
     size_t slab_bytes = 0;
+    bool timing = false;
+    std::vector<hipEvent_t> events;  // start/stop pairs around force launches
+    size_t events_used = 0;
 };
 
 namespace {
@@ -125,7 +129,28 @@ void launch_lds(const nbk::ForceParams& p, dim3 grid, hipStream_t st)
     nbk::force_lds<M, TILE, 8, 1><<<grid, nbk::kWG, 0, st>>>(p);
 }
 
+int time_mark(nbody_ctx* c)
+{
+    if (!c->timing) return NBODY_OK;
+    if (c->events_used == c->events.size()) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        c->events.push_back(e);
+    }
+    HIP_TRY(hipEventRecord(c->events[c->events_used++], c->stream));
+    return NBODY_OK;
+}
+
+int launch_force_untimed(nbody_ctx* c, const Shape& s, const nbk::ForceParams& p);
+
 int launch_force(nbody_ctx* c, const Shape& s, const nbk::ForceParams& p)
+{
+    if (int rc = time_mark(c)) return rc;
+    if (int rc = launch_force_untimed(c, s, p)) return rc;
+    return time_mark(c);
+}
+
+int launch_force_untimed(nbody_ctx* c, const Shape& s, const nbk::ForceParams& p)
 {
     if (p.i1 <= p.i0) return NBODY_OK;
     if (c->kernel == NBODY_KERNEL_STRICT) {
@@ -219,9 +244,10 @@ int nbody_ctx_create(nbody_ctx** out, int device)
 int nbody_ctx_destroy(nbody_ctx* c)
 {
     if (!c) return NBODY_OK;
-    hipSetDevice(c->device);
-    if (c->slabs) hipFree(c->slabs);
-    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    (void)hipSetDevice(c->device);
+    if (c->slabs) (void)hipFree(c->slabs);
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return NBODY_OK;
 }
@@ -397,6 +423,31 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
         nbk::integrate<<<iblocks, nbk::kWG, 0, c->stream>>>(q);
     }
     HIP_TRY(hipGetLastError());
+    return NBODY_OK;
+}
+
+int nbody_ctx_timing(nbody_ctx* c, int enable)
+{
+    if (int rc = check_ctx(c)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->timing = enable != 0;
+    c->events_used = 0;
+    return NBODY_OK;
+}
+
+int nbody_ctx_timing_read(nbody_ctx* c, double* force_ms, int* launches)
+{
+    if (int rc = check_ctx(c)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double total = 0.0;
+    for (size_t k = 0; k + 1 < c->events_used; k += 2) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->events[k], c->events[k + 1]));
+        total += ms;
+    }
+    if (force_ms) *force_ms = total;
+    if (launches) *launches = (int)(c->events_used / 2);
+    c->events_used = 0;
     return NBODY_OK;
 }
 

@@ -126,6 +126,16 @@ class Context:
     def sync(self) -> None:
         check(self._lib.nbody_ctx_sync(self._h))
 
+    def timing(self, enable: bool) -> None:
+        """Bracket every force launch with hipEvents on the launch stream (bench.py's roofline)."""
+        check(self._lib.nbody_ctx_timing(self._h, 1 if enable else 0))
+
+    def timing_read(self):
+        """(summed force-kernel ms, launches) since the last read; synchronises the stream."""
+        ms, k = C.c_double(), C.c_int()
+        check(self._lib.nbody_ctx_timing_read(self._h, C.byref(ms), C.byref(k)))
+        return ms.value, k.value
+
     def close(self) -> None:
         if self._h:
             self._lib.nbody_ctx_destroy(self._h)

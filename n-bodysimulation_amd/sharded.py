@@ -1,0 +1,154 @@
+"""Multi-GPU step: bodies block-partitioned over the ranks of one node, one all-gather of
+positions per step, overlapped with the local-block force pass.
+
+The reference is single-device (device 0 hard-coded: TestProject/kernel.cu:630); this is the
+build's own decomposition:
+
+    rank r owns the contiguous index block [r*S, (r+1)*S), S = ceil(N / G)
+    every rank holds the whole position/mass array X_full (16 B/body: 16 MiB at N = 1 M)
+    V and A of the own block never leave the rank
+
+    per step, on rank r                        stream
+      all_gather(X_full <- own block)            comm     (in place, S*16 B per rank)
+      A  = forces(own targets, own sources)      compute  (overlaps the all-gather)
+      wait(all_gather)
+      A += forces(own targets, sources before the block)
+      A += forces(own targets, sources after the block)
+      v += (dt/2) a ; x += dt v  (own block)     compute
+      -> event for the next step's all-gather
+
+The remote passes of step n end before the integrate of step n (same stream), and the
+all-gather of step n+1 waits on that integrate, so no second position buffer is needed.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, over xGMI). All compute
+goes through a *backend*: ``HipBackend`` (the C-ABI, the only backend the product ships).
+``tests/`` inject a CPU checker backend to exercise this schedule under ``gloo`` without a GPU.
+Padding bodies (when G does not divide N) are massless and sit on the first body, so they add
+exactly +-0 to every sum.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from ._lib import KERNEL_FAST
+
+
+class HipBackend:
+    """Force/integrate on the rank's GPU through libnbody_hip.so, with a compute stream (the
+    context's launch stream) and a communication stream for the all-gather."""
+
+    def __init__(self, device: torch.device, dt: float, eps2: float, kernel: int = KERNEL_FAST, **kernel_opts):
+        from .engine import Context
+        self.device = device
+        torch.cuda.set_device(device)
+        self.compute = torch.cuda.Stream(device=device)
+        self.comm = torch.cuda.Stream(device=device)
+        self.ctx = Context(device=device.index, dt=dt, eps2=eps2, kernel=kernel, stream=self.compute, **kernel_opts)
+        self._integrated = torch.cuda.Event()
+        self._gathered = torch.cuda.Event()
+
+    def empty(self, n: int) -> torch.Tensor:
+        return torch.zeros((n, 4), dtype=torch.float32, device=self.device)
+
+    def from_numpy(self, a: np.ndarray) -> torch.Tensor:
+        return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.device)
+
+    def accel_range(self, x, a_own, i0, i1, j0, j1, accumulate):
+        self.ctx.accel_range(x, a_own, i0, i1, j0, j1, accumulate)
+
+    def integrate_range(self, x, v_own, a_own, i0, i1):
+        self.ctx.integrate_range(x, v_own, a_own, i0, i1)
+
+    # -- stream choreography ---------------------------------------------------------------
+    def all_gather(self, x_full: torch.Tensor, i0: int, i1: int, group) -> None:
+        """Start the in-place all-gather of the own block on the comm stream, after the
+        integrate that produced it."""
+        self.comm.wait_event(self._integrated)
+        with torch.cuda.stream(self.comm):
+            dist.all_gather_into_tensor(x_full, x_full[i0:i1], group=group)
+            self._gathered.record(self.comm)
+
+    def wait_gather(self) -> None:
+        self.compute.wait_event(self._gathered)
+
+    def mark_integrated(self) -> None:
+        self._integrated.record(self.compute)
+
+    def sync(self) -> None:
+        self.compute.synchronize()
+        self.comm.synchronize()
+
+
+class ShardedSimulation:
+    """`steps` x (all-gather, local forces, remote forces, integrate) over the ranks of `group`."""
+
+    def __init__(self, bodies: np.ndarray, dt: float = _lib.DEFAULT_DT, eps2: float = _lib.DEFAULT_EPS2,
+                 group=None, backend=None, kernel: int = KERNEL_FAST, **kernel_opts):
+        bodies = np.ascontiguousarray(bodies, np.float32)
+        if bodies.ndim != 2 or bodies.shape[1] != 4:
+            raise ValueError("bodies must be (n,4) float32 {x,y,z,mass}")
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.n = bodies.shape[0]
+        self.shard = (self.n + self.world - 1) // self.world
+        self.n_pad = self.shard * self.world
+        self.i0 = self.rank * self.shard
+        self.i1 = self.i0 + self.shard
+        if backend is None:
+            if not torch.cuda.is_available():
+                raise _lib.NBodyError(_lib.ERR_HIP, "no HIP device: the sharded step has no CPU path")
+            local = self.rank % max(torch.cuda.device_count(), 1)
+            backend = HipBackend(torch.device("cuda", local), dt, eps2, kernel=kernel, **kernel_opts)
+        self.backend = backend
+        padded = np.zeros((self.n_pad, 4), np.float32)
+        padded[: self.n] = bodies
+        if self.n_pad > self.n and self.n > 0:
+            padded[self.n:, :3] = bodies[0, :3]  # massless, on top of body 0: contributes +-0
+        self.x = backend.from_numpy(padded)          # every rank starts from the same full array
+        self.v = backend.empty(self.shard)
+        self.a = backend.empty(self.shard)
+        self._fresh = True                           # X_full already consistent: skip first gather
+        backend.mark_integrated()
+
+    def step(self, steps: int = 1) -> None:
+        b = self.backend
+        for _ in range(steps):
+            gather = self.world > 1 and not self._fresh
+            if gather:
+                b.all_gather(self.x, self.i0, self.i1, self.group)
+            b.accel_range(self.x, self.a, self.i0, self.i1, self.i0, self.i1, False)
+            if gather:
+                b.wait_gather()
+            if self.i0 > 0:
+                b.accel_range(self.x, self.a, self.i0, self.i1, 0, self.i0, True)
+            if self.i1 < self.n_pad:
+                b.accel_range(self.x, self.a, self.i0, self.i1, self.i1, self.n_pad, True)
+            b.integrate_range(self.x, self.v, self.a, self.i0, self.i1)
+            b.mark_integrated()
+            self._fresh = False
+
+    def sync(self) -> None:
+        self.backend.sync()
+
+    def gather_state(self):
+        """(x, v, a) of all N bodies on every rank, as numpy arrays (test/diagnostic helper)."""
+        self.sync()
+        outs = []
+        if self.world > 1:
+            # bring X_full up to date first (the own block was advanced by the last integrate)
+            xs = [torch.empty_like(self.x[self.i0:self.i1]) for _ in range(self.world)]
+            dist.all_gather(xs, self.x[self.i0:self.i1].contiguous(), group=self.group)
+            outs.append(torch.cat(xs))
+            for t in (self.v, self.a):
+                parts = [torch.empty_like(t) for _ in range(self.world)]
+                dist.all_gather(parts, t.contiguous(), group=self.group)
+                outs.append(torch.cat(parts))
+        else:
+            outs = [self.x, self.v, self.a]
+        return tuple(o.cpu().numpy()[: self.n] for o in outs)

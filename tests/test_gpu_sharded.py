@@ -1,0 +1,86 @@
+"""The sharded step on the GPU: a 1-rank RCCL group (the only world size a 1-GPU box allows), and
+the 2- and 3-block decomposition driven by hand on one device (same C-ABI calls a rank makes)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+from conftest import same_bits
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_one_rank_nccl_group_equals_single_gpu(nb):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        n = 5000
+        x0 = nb.engine.seeded_bodies(n, 1, 9)
+        sh = nb.sharded.ShardedSimulation(x0, dt=0.01, eps2=0.002)
+        sh.step(4)
+        xs, vs, as_ = sh.gather_state()
+        sim = nb.engine.Simulation(x0, dt=0.01, eps2=0.002)
+        sim.run(4)
+        x, v, a = sim.state()
+        assert np.abs(xs - x)[:, :3].max() <= 1e-6
+        assert np.abs(as_ - a)[:, :3].max() / np.abs(a[:, :3]).max() <= 1e-5
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("blocks,kernel", [(2, "strict"), (3, "strict"), (2, "fast"), (8, "fast")])
+def test_block_decomposition_on_one_device(nb, oracle, blocks, kernel):
+    """Each 'rank' = one context on the same GPU; the all-gather is a device copy. Strict kernel in
+    canonical block order is bit-identical to the single-device Jacobi oracle."""
+    n, steps, dt = 2040, 2, 0.1   # divisible by 2, 3 and 8
+    x0 = nb.engine.seeded_bodies(n, 0, 17)
+    k = nb.KERNEL_STRICT if kernel == "strict" else nb.KERNEL_FAST
+    S = n // blocks
+    ranks = []
+    for r in range(blocks):
+        ctx = nb.engine.Context(dt=dt, kernel=k)
+        ranks.append(dict(ctx=ctx, x=torch.from_numpy(x0).cuda(), v=torch.zeros((S, 4), device="cuda"),
+                          a=torch.zeros((S, 4), device="cuda"), i0=r * S, i1=(r + 1) * S))
+    for _ in range(steps):
+        for R in ranks:
+            c = R["ctx"]
+            if kernel == "strict":   # canonical order: the running sum continues block after block
+                c.accel_range(R["x"], R["a"], R["i0"], R["i1"], 0, n, False)
+            else:                    # the schedule of sharded.py: own block, then before, then after
+                c.accel_range(R["x"], R["a"], R["i0"], R["i1"], R["i0"], R["i1"], False)
+                if R["i0"] > 0:
+                    c.accel_range(R["x"], R["a"], R["i0"], R["i1"], 0, R["i0"], True)
+                if R["i1"] < n:
+                    c.accel_range(R["x"], R["a"], R["i0"], R["i1"], R["i1"], n, True)
+            c.integrate_range(R["x"], R["v"], R["a"], R["i0"], R["i1"])
+            c.sync()
+        # "all-gather": every rank receives every other rank's advanced block
+        for R in ranks:
+            for Q in ranks:
+                if Q is not R:
+                    R["x"][Q["i0"]:Q["i1"]] = Q["x"][Q["i0"]:Q["i1"]]
+        torch.cuda.synchronize()
+    xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
+    oracle.step_jacobi(xo, ao, vo, dt=dt, eps2=0.002, steps=steps)
+    xg = ranks[0]["x"].cpu().numpy()
+    ag = torch.cat([R["a"] for R in ranks]).cpu().numpy()
+    vg = torch.cat([R["v"] for R in ranks]).cpu().numpy()
+    if kernel == "strict":
+        assert same_bits(xg, xo) and same_bits(vg, vo) and same_bits(ag, ao)
+    else:
+        assert np.abs(xg - xo)[:, :3].max() / 1e5 <= 1e-6
+        assert np.abs(ag - ao)[:, :3].max() / np.abs(ao[:, :3]).max() <= 1e-5
+    for R in ranks[1:]:
+        assert np.array_equal(R["x"].cpu().numpy(), xg)
