@@ -59,6 +59,11 @@ struct MathScalar {
     }
     __device__ __forceinline__ float4 acc(int k) const { return make_float4(ax[k], ay[k], az[k], 0.0f); }
 
+    __device__ __forceinline__ void pair4(const float sx, const float sy, const float sz, const float sm, const float eps2)
+    {
+        pair(make_float4(sx, sy, sz, sm), eps2);
+    }
+
     __device__ __forceinline__ void pair(const float4 bj, const float eps2)
     {
 #pragma unroll
@@ -104,7 +109,12 @@ struct MathPacked {
 
     __device__ __forceinline__ void pair(const float4 bj, const float eps2)
     {
-        const f32x2 bx = {bj.x, bj.x}, by = {bj.y, bj.y}, bz = {bj.z, bj.z}, bm = {bj.w, bj.w};
+        pair4(bj.x, bj.y, bj.z, bj.w, eps2);
+    }
+
+    __device__ __forceinline__ void pair4(const float sx, const float sy, const float sz, const float sm, const float eps2)
+    {
+        const f32x2 bx = {sx, sx}, by = {sy, sy}, bz = {sz, sz}, bm = {sm, sm};
         const f32x2 e2 = {eps2, eps2};
 #pragma unroll
         for (int k = 0; k < H; ++k) {
@@ -168,12 +178,17 @@ __device__ __forceinline__ void store_targets(const ForceParams& p, int ibase, i
 }
 
 // LDS-tiled force kernel. grid = (ceil((i1-i0) / (256*BPL)), nslab).
-template <class M, int TILE, int UNROLL, int MINW>
+// LAYOUT of a source in the LDS tile: 0 = {x,y,z,m} (one ds_read_b128), 1 = {x,y,m,z},
+// 2 = two 8-byte halves {x,y} | {z,m} in separate arrays. Same arithmetic; they differ only in
+// how many v_mov / s_nop hipcc adds around the op_sel broadcasts (measured in tools/kbench.hip).
+template <class M, int TILE, int UNROLL, int MINW, int LAYOUT = 0>
 __global__ void __launch_bounds__(kWG, MINW) force_lds(const ForceParams p)
 {
     static_assert(TILE % kWG == 0, "tile must be a multiple of the workgroup");
     constexpr int LPT = TILE / kWG;  // float4 loads per thread per tile
     __shared__ float4 sh[2][TILE];
+    float2* const sh_xy = reinterpret_cast<float2*>(&sh[0][0]);             // LAYOUT 2: [2][TILE] halves
+    float2* const sh_zm = reinterpret_cast<float2*>(&sh[0][0]) + 2 * TILE;
 
     const int tid = threadIdx.x;
     const int ibase = p.i0 + blockIdx.x * (kWG * M::BPL);
@@ -197,12 +212,32 @@ __global__ void __launch_bounds__(kWG, MINW) force_lds(const ForceParams p)
     int buf = 0;
     for (int jt = ja; jt < jb; jt += TILE, buf ^= 1) {
 #pragma unroll
-        for (int l = 0; l < LPT; ++l) sh[buf][l * kWG + tid] = pre[l];
+        for (int l = 0; l < LPT; ++l) {
+            const int e = l * kWG + tid;
+            if (LAYOUT == 0) sh[buf][e] = pre[l];
+            if (LAYOUT == 1) sh[buf][e] = make_float4(pre[l].x, pre[l].y, pre[l].w, pre[l].z);
+            if (LAYOUT == 2) {
+                sh_xy[buf * TILE + e] = make_float2(pre[l].x, pre[l].y);
+                sh_zm[buf * TILE + e] = make_float2(pre[l].z, pre[l].w);
+            }
+        }
         __syncthreads();  // one barrier per tile: the other buffer is only rewritten after
                           // every wave has passed the NEXT barrier, i.e. finished this tile
         if (jt + TILE < jb) fetch(jt + TILE);
 #pragma unroll UNROLL
-        for (int jj = 0; jj < TILE; ++jj) t.pair(sh[buf][jj], p.eps2);
+        for (int jj = 0; jj < TILE; ++jj) {
+            if (LAYOUT == 0) t.pair(sh[buf][jj], p.eps2);
+            if (LAYOUT == 1) {
+                const float4 s = sh[buf][jj];
+                t.pair4(s.x, s.y, s.w, s.z, p.eps2);
+            }
+            if (LAYOUT == 2) {
+                f32x2 a = *reinterpret_cast<const f32x2*>(&sh_xy[buf * TILE + jj]);
+                f32x2 b = *reinterpret_cast<const f32x2*>(&sh_zm[buf * TILE + jj]);
+                asm volatile("" : "+v"(a), "+v"(b));  // keep each half in a 64-bit pair of its own
+                t.pair4(a.x, a.y, b.x, b.y, p.eps2);
+            }
+        }
     }
     store_targets(p, ibase, blockIdx.y, t);
 }

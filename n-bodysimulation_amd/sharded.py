@@ -70,7 +70,14 @@ class HipBackend:
         integrate that produced it."""
         self.comm.wait_event(self._integrated)
         with torch.cuda.stream(self.comm):
-            dist.all_gather_into_tensor(x_full, x_full[i0:i1], group=group)
+            if dist.get_backend(group) == "nccl":
+                dist.all_gather_into_tensor(x_full, x_full[i0:i1], group=group)   # RCCL, in place
+            else:
+                # gloo (rehearsals on a box without one GPU per rank): stage through a list
+                world = dist.get_world_size(group)
+                parts = [torch.empty_like(x_full[i0:i1]) for _ in range(world)]
+                dist.all_gather(parts, x_full[i0:i1].clone(), group=group)
+                x_full.copy_(torch.cat(parts))
             self._gathered.record(self.comm)
 
     def wait_gather(self) -> None:

@@ -84,3 +84,46 @@ def test_block_decomposition_on_one_device(nb, oracle, blocks, kernel):
         assert np.abs(ag - ao)[:, :3].max() / np.abs(ao[:, :3]).max() <= 1e-5
     for R in ranks[1:]:
         assert np.array_equal(R["x"].cpu().numpy(), xg)
+
+
+def _gloo_gpu_worker(rank, world, port, n, steps, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import nbody_amd
+        x0 = nbody_amd.engine.seeded_bodies(n, 1, 77)
+        be = nbody_amd.sharded.HipBackend(torch.device("cuda", 0), 0.01, 0.002)   # every rank on the one GPU
+        sim = nbody_amd.sharded.ShardedSimulation(x0, dt=0.01, eps2=0.002, backend=be)
+        sim.step(steps)
+        x, v, a = sim.gather_state()
+        q.put((rank, x, v, a))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 6000), (3, 5001)])
+def test_sharded_hip_backend_multi_rank_over_gloo(nb, oracle, world, n):
+    """The real HipBackend (streams, events, C-ABI calls, padding) with several ranks; the box has one
+    GPU, so all ranks share it and the collective goes over gloo instead of RCCL."""
+    import torch.multiprocessing as mp
+    steps = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_gpu_worker, args=(r, world, port, n, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    x0 = nb.engine.seeded_bodies(n, 1, 77)
+    xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
+    oracle.step_jacobi(xo, ao, vo, dt=0.01, eps2=0.002, steps=steps)
+    for rank, x, v, a in res:
+        assert np.abs(x - xo)[:, :3].max() <= 1e-6
+        assert np.abs(a - ao)[:, :3].max() / np.abs(ao[:, :3]).max() <= 1e-5
+        assert np.array_equal(x, res[0][1])

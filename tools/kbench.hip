@@ -145,14 +145,14 @@ struct Variant {
     std::function<void(const nbk::ForceParams&, int nslab)> launch;
 };
 
-template <class M, int TILE, int UNROLL, int MINW>
+template <class M, int TILE, int UNROLL, int MINW, int LAYOUT = 0>
 static Variant v_lds(const char* mname)
 {
     char nm[64];
-    snprintf(nm, sizeof nm, "lds  %s bpl%d tile%-4d u%-2d w%d", mname, M::BPL, TILE, UNROLL, MINW);
+    snprintf(nm, sizeof nm, "lds%d %s bpl%d tile%-4d u%-2d w%d", LAYOUT, mname, M::BPL, TILE, UNROLL, MINW);
     return {nm, M::BPL, [](const nbk::ForceParams& p, int nslab) {
                 dim3 g((p.i1 - p.i0 + 256 * M::BPL - 1) / (256 * M::BPL), nslab);
-                nbk::force_lds<M, TILE, UNROLL, MINW><<<g, 256>>>(p);
+                nbk::force_lds<M, TILE, UNROLL, MINW, LAYOUT><<<g, 256>>>(p);
             }};
 }
 template <class M, int UNROLL, int MINW>
@@ -217,7 +217,7 @@ int main(int argc, char** argv)
         hx[i] = make_float4(u() * 2e5f - 1e5f, u() * 2e5f - 1e5f, u() * 2e5f - 1e5f, 1e5f + u() * (1e9f - 1e5f));
     }
     float4 *dx, *dout, *dref;
-    const int max_slab = 16;
+    const int max_slab = 32;
     CK(hipMalloc(&dx, sizeof(float4) * n));
     CK(hipMalloc(&dout, sizeof(float4) * (size_t)n * max_slab));
     CK(hipMalloc(&dref, sizeof(float4) * n));
@@ -235,25 +235,23 @@ int main(int argc, char** argv)
            (double)n * n / (ms_strict * 1e-3));
 
     std::vector<Variant> vs = {
-        v_lds<S1, 256, 4, 1>("S"),   v_lds<S1, 1024, 8, 1>("S"),  v_lds<S2, 1024, 8, 1>("S"),
-        v_lds<S4, 512, 4, 1>("S"),   v_lds<S4, 1024, 4, 1>("S"),  v_lds<S4, 1024, 8, 1>("S"),  v_lds<S4, 1024, 16, 1>("S"),
-        v_lds<S8, 1024, 4, 1>("S"),  v_lds<S8, 1024, 8, 1>("S"),
-        v_lds<P2, 1024, 8, 1>("P"),  v_lds<P4, 512, 4, 1>("P"),   v_lds<P4, 1024, 4, 1>("P"),  v_lds<P4, 1024, 8, 1>("P"),
-        v_lds<P4, 1024, 16, 1>("P"), v_lds<P8, 1024, 4, 1>("P"),  v_lds<P8, 1024, 8, 1>("P"),  v_lds<P4, 2048, 8, 1>("P"),
-        v_sgpr<S1, 8, 1>("S"),       v_sgpr<S2, 8, 1>("S"),       v_sgpr<S4, 4, 1>("S"),       v_sgpr<S4, 8, 1>("S"),
-        v_sgpr<S8, 4, 1>("S"),       v_sgpr<S8, 8, 1>("S"),
-        v_sgpr<P2, 8, 1>("P"),       v_sgpr<P4, 4, 1>("P"),       v_sgpr<P4, 8, 1>("P"),       v_sgpr<P4, 16, 1>("P"),
-        v_sgpr<P8, 4, 1>("P"),       v_sgpr<P8, 8, 1>("P"),
+        v_lds<P4, 1024, 8, 1, 0>("P"), v_lds<P4, 1024, 8, 1, 1>("P"), v_lds<P4, 1024, 8, 1, 2>("P"),
+        v_lds<P4, 2048, 8, 1, 0>("P"), v_lds<P4, 2048, 8, 1, 1>("P"), v_lds<P4, 2048, 8, 1, 2>("P"),
+        v_lds<P4, 512, 8, 1, 0>("P"),  v_lds<P4, 512, 8, 1, 1>("P"),  v_lds<P4, 512, 8, 1, 2>("P"),
+        v_lds<P4, 1024, 4, 1, 1>("P"), v_lds<P4, 1024, 16, 1, 1>("P"), v_lds<P4, 1024, 8, 2, 1>("P"),
+        v_lds<P8, 1024, 8, 1, 0>("P"), v_lds<P8, 1024, 8, 1, 1>("P"), v_lds<P8, 1024, 4, 1, 1>("P"),
+        v_lds<P2, 1024, 8, 1, 0>("P"), v_lds<P2, 1024, 8, 1, 1>("P"), v_lds<P2, 1024, 16, 1, 1>("P"),
+        v_sgpr<P4, 4, 1>("P"),        v_sgpr<P2, 8, 1>("P"),
     };
     p.out = dout;
     printf("%-34s %5s %9s %12s %8s %10s\n", "variant", "slabs", "ms", "pairs/s", "%peak20", "max rel err");
     double amax = 0;
     for (int i = 0; i < n; ++i) amax = std::max({amax, (double)fabsf(href[i].x), (double)fabsf(href[i].y), (double)fabsf(href[i].z)});
     for (auto& v : vs) {
-        for (int nslab : {1, 2, 4, 8, 16}) {
+        for (int nslab : {4, 8, 16, 32}) {
             // keep roughly 2..16 waves per SIMD worth of work
             double waves = (double)n / (64.0 * v.bpl) * nslab;
-            if (waves < 1024 * 1.5 || waves > 1024 * 16) continue;
+            if (waves < 1024 * 1.5 || waves > 1024 * 33) continue;
             float ms = time_ms([&] { v.launch(p, nslab); }, 3);
             CK(hipMemcpy(hout.data(), dout, sizeof(float4) * (size_t)n * nslab, hipMemcpyDeviceToHost));
             double err = 0;
