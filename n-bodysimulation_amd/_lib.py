@@ -81,6 +81,14 @@ def load() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: build the HIP library first "
                 "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (torch/lib) while
+        # this library's DT_NEEDED resolves to /opt/rocm's. If torch is imported first the loader
+        # reuses torch's copy for us (same SONAME) and streams/events/pointers are shared; the other
+        # order maps two runtimes, and whichever initialises second sees "no ROCm-capable device".
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError here = header/library mismatch

@@ -1,0 +1,178 @@
+// nbody_headless.cpp — the reference's headless run (TestProject/main.cpp:231-368, the
+// enableVisualization == false branch) as a non-interactive host program on top of the C-ABI.
+//
+//   main.cpp step                                   here
+//   cudaMallocHost x3, fill_with_random4/zeroes4    nbody_malloc_host, --init libc|ref|plummer   (:250-272)
+//   cudaMalloc + cudaMemcpy H2D x3                  nbody_malloc_device, nbody_memcpy_h2d         (:275-283,352-354)
+//   askForKernelType / Visualization / StepsNumber  argv; --interactive reads the same three answers (:163-228)
+//   simulationLoopNoVisual                          `steps` x simulate() (--sync-each-step) or one queued nbody_step (:142-160)
+//   (results discarded, no timing)                  D2H, --dump state, timing, one JSON line
+//   cudaFree / cudaFreeHost                         nbody_free_*                                   (:358-366)
+//
+// State files (--dump P / --load P): P.json {n, steps_done, dt, eps2} + P.x.f4 / P.v.f4 / P.a.f4,
+// raw little-endian float4[N] — exactly the three arrays main.cpp owns (main.cpp:232-241).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "nbody.h"
+
+struct float4 { float x, y, z, w; };
+#include "nbody_compat.hpp"
+
+static void die(const std::string& m)
+{
+    std::cerr << m << std::endl;
+    std::exit(EXIT_FAILURE);
+}
+static void ok(int rc)
+{
+    if (rc != NBODY_OK) die(std::string("nbody: ") + nbody_last_error());
+}
+
+static bool write_file(const std::string& path, const void* p, size_t bytes)
+{
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    const bool good = std::fwrite(p, 1, bytes, f) == bytes;
+    std::fclose(f);
+    return good;
+}
+static bool read_file(const std::string& path, void* p, size_t bytes)
+{
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    const bool good = std::fread(p, 1, bytes, f) == bytes;
+    std::fclose(f);
+    return good;
+}
+
+int main(int argc, char** argv)
+{
+    int n = N_BODIES, steps = 10, kernel = NBODY_KERNEL_FAST, sync_each = 0, interactive = 0, json = 1;
+    long steps_done = 0;
+    float dt = DT, eps2 = EPS2;
+    unsigned long long seed = 12345;
+    std::string init = "libc", dump, load;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto val = [&]() -> const char* { if (i + 1 >= argc) die("missing value for " + a); return argv[++i]; };
+        if (a == "--n") n = std::atoi(val());
+        else if (a == "--steps") steps = std::atoi(val());
+        else if (a == "--dt") dt = (float)std::atof(val());
+        else if (a == "--eps2") eps2 = (float)std::atof(val());
+        else if (a == "--seed") seed = std::strtoull(val(), nullptr, 10);
+        else if (a == "--init") init = val();            // libc (utils.cpp:30-37) | ref | plummer
+        else if (a == "--kernel") { std::string k = val(); kernel = (k == "strict" || k == "1") ? NBODY_KERNEL_STRICT : NBODY_KERNEL_FAST; }
+        else if (a == "--dump") dump = val();
+        else if (a == "--load") load = val();
+        else if (a == "--sync-each-step") sync_each = 1;
+        else if (a == "--interactive") interactive = 1;
+        else if (a == "--quiet") json = 0;
+        else die("unknown option " + a + "\nusage: nbody_headless [--n N] [--steps K] [--dt f] [--eps2 f] [--init libc|ref|plummer] [--seed S]"
+                 " [--kernel fast|strict] [--dump P] [--load P] [--sync-each-step] [--interactive]");
+    }
+    if (interactive) {
+        // the reference's three prompts (main.cpp:163-228); only the headless all-pairs answers run here
+        std::string s;
+        std::cout << "Choose the kernel (0 = basic all-pairs, 1 = reduction): ";
+        std::getline(std::cin, s);
+        if (s != "0") die("only the basic all-pairs kernel (0) is built; the reduction kernels need the visual path");
+        std::cout << "Enable visualization? (y/n): ";
+        std::getline(std::cin, s);
+        if (s != "n" && s != "N") die("visualization is out of scope of this build; answer n");
+        std::cout << "Number of steps: ";
+        std::getline(std::cin, s);
+        steps = std::atoi(s.c_str());
+    }
+    if (n < 0 || steps < 0) die("n and steps must be >= 0");
+    const size_t bytes = sizeof(float4) * (size_t)n;
+
+    float4 *bodies = nullptr, *velocity = nullptr, *accelerations = nullptr;
+    ok(nbody_malloc_host((void**)&bodies, bytes));
+    ok(nbody_malloc_host((void**)&velocity, bytes));
+    ok(nbody_malloc_host((void**)&accelerations, bytes));
+    if (!load.empty()) {
+        if (!read_file(load + ".x.f4", bodies, bytes) || !read_file(load + ".v.f4", velocity, bytes))
+            die("cannot read state " + load + ".{x,v}.f4 for n=" + std::to_string(n));
+        fill_with_zeroes4(accelerations, n);
+        if (FILE* f = std::fopen((load + ".json").c_str(), "r")) {
+            char buf[512] = {0};
+            if (std::fread(buf, 1, sizeof buf - 1, f) > 0)
+                if (const char* p = std::strstr(buf, "\"steps_done\":")) steps_done = std::atol(p + 13);
+            std::fclose(f);
+        }
+    } else {
+        if (init == "libc") fill_with_random4(bodies, n);
+        else if (init == "ref") ok(nbody_fill_seeded((nbody_float4*)bodies, n, 0, seed));
+        else if (init == "plummer") ok(nbody_fill_seeded((nbody_float4*)bodies, n, 1, seed));
+        else die("unknown --init " + init);
+        fill_with_zeroes4(velocity, n);
+        fill_with_zeroes4(accelerations, n);
+    }
+
+    float4 *d_bodies = nullptr, *d_velocity = nullptr, *d_accelerations = nullptr;
+    ok(nbody_malloc_device((void**)&d_velocity, bytes));
+    ok(nbody_malloc_device((void**)&d_accelerations, bytes));
+    ok(nbody_malloc_device((void**)&d_bodies, bytes));
+    ok(nbody_memcpy_h2d(d_velocity, velocity, bytes));
+    ok(nbody_memcpy_h2d(d_accelerations, accelerations, bytes));
+    ok(nbody_memcpy_h2d(d_bodies, bodies, bytes));
+
+    nbody_ctx* ctx = nullptr;
+    ok(nbody_default_ctx(&ctx));                         // the context simulate() uses
+    ok(nbody_ctx_set_params(ctx, dt, eps2));
+    ok(nbody_ctx_set_kernel(ctx, kernel, 0, 0, 0));
+    ok(nbody_ctx_reserve(ctx, n));
+
+    std::printf("Starting the simulation...\n");         // main.cpp:145
+    const auto t0 = std::chrono::steady_clock::now();
+    if (sync_each) {
+        for (int counter = 0; counter < steps; ++counter) {   // the reference's loop, one sync per step
+            try {
+                simulate(d_bodies, d_accelerations, d_velocity, n);
+            } catch (const std::exception& e) {
+                std::cerr << e.what() << std::endl;
+                return EXIT_FAILURE;
+            }
+        }
+    } else {
+        ok(nbody_step(ctx, (nbody_float4*)d_bodies, (nbody_float4*)d_accelerations, (nbody_float4*)d_velocity, n, steps));
+        ok(nbody_ctx_sync(ctx));
+    }
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::printf("Simulation complete\n");                // main.cpp:158
+
+    ok(nbody_memcpy_d2h(bodies, d_bodies, bytes));
+    ok(nbody_memcpy_d2h(velocity, d_velocity, bytes));
+    ok(nbody_memcpy_d2h(accelerations, d_accelerations, bytes));
+    if (!dump.empty()) {
+        if (!write_file(dump + ".x.f4", bodies, bytes) || !write_file(dump + ".v.f4", velocity, bytes) ||
+            !write_file(dump + ".a.f4", accelerations, bytes))
+            die("cannot write state " + dump);
+        char hdr[256];
+        std::snprintf(hdr, sizeof hdr, "{\"n\": %d, \"steps_done\": %ld, \"dt\": %.9g, \"eps2\": %.9g, \"dtype\": \"f32\", \"layout\": \"float4 x,y,z,w LE\"}\n",
+                      n, steps_done + steps, dt, eps2);
+        if (!write_file(dump + ".json", hdr, std::strlen(hdr))) die("cannot write " + dump + ".json");
+    }
+    if (json) {
+        const double pairs = (double)n * (double)n * steps;
+        std::printf("{\"n\": %d, \"steps\": %d, \"dt\": %.9g, \"eps2\": %.9g, \"kernel\": \"%s\", \"seconds\": %.6f, \"pairs_per_s\": %.6g, "
+                    "\"gflops_at_20\": %.6g, \"body0\": [%.9g, %.9g, %.9g, %.9g]}\n",
+                    n, steps, dt, eps2, kernel == NBODY_KERNEL_STRICT ? "strict" : "fast", secs, secs > 0 ? pairs / secs : 0.0,
+                    secs > 0 ? 20.0 * pairs / secs / 1e9 : 0.0, n ? bodies[0].x : 0.f, n ? bodies[0].y : 0.f, n ? bodies[0].z : 0.f,
+                    n ? bodies[0].w : 0.f);
+    }
+    ok(nbody_free_device(d_bodies));
+    ok(nbody_free_device(d_velocity));
+    ok(nbody_free_device(d_accelerations));
+    ok(nbody_free_host(bodies));
+    ok(nbody_free_host(velocity));
+    ok(nbody_free_host(accelerations));
+    return 0;
+}

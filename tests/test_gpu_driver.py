@@ -1,0 +1,89 @@
+"""The C++ host programs over the C-ABI: the headless driver (main.cpp's headless branch) and the
+compareHostToDevice checker program (validation.cpp:55-103)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "n-bodysimulation_amd", "bin", "nbody_headless")
+HARNESS = os.path.join(ROOT, "oracle", "compare_host_device")
+
+
+def _run(cmd, **kw):
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, **kw)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
+
+
+def _f4(path, n):
+    return np.fromfile(path, np.float32).reshape(n, 4)
+
+
+def test_headless_matches_python_host_layer_bitwise(nb, tmp_path):
+    n, steps = 3000, 5
+    out = _run([DRIVER, "--n", str(n), "--steps", str(steps), "--init", "ref", "--seed", "99", "--dump", str(tmp_path / "s")])
+    assert "Starting the simulation..." in out and "Simulation complete" in out     # main.cpp:145,158
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line["n"] == n and line["steps"] == steps and line["pairs_per_s"] > 0
+    sim = nb.engine.Simulation(nb.engine.seeded_bodies(n, 0, 99))                    # DT/EPS2 defaults of constants.h
+    sim.run(steps)
+    x, v, a = sim.state()
+    assert np.array_equal(_f4(tmp_path / "s.x.f4", n), x)
+    assert np.array_equal(_f4(tmp_path / "s.v.f4", n), v)
+    assert np.array_equal(_f4(tmp_path / "s.a.f4", n), a)
+    hdr = json.load(open(tmp_path / "s.json"))
+    assert hdr["n"] == n and hdr["steps_done"] == steps
+
+
+def test_headless_dump_load_resume_is_exact(tmp_path):
+    n = 2048
+    base = ["--n", str(n), "--init", "plummer", "--dt", "0.01", "--quiet"]
+    _run([DRIVER, *base, "--steps", "5", "--dump", str(tmp_path / "full")])
+    _run([DRIVER, *base, "--steps", "3", "--dump", str(tmp_path / "half")])
+    _run([DRIVER, *base, "--steps", "2", "--load", str(tmp_path / "half"), "--dump", str(tmp_path / "resumed")])
+    for ext in ("x", "v", "a"):
+        assert np.array_equal(_f4(tmp_path / f"full.{ext}.f4", n), _f4(tmp_path / f"resumed.{ext}.f4", n)), ext
+    assert json.load(open(tmp_path / "resumed.json"))["steps_done"] == 5
+
+
+def test_headless_reference_loop_and_prompts(tmp_path):
+    """--sync-each-step is the reference's loop (one synchronous simulate() per step); --interactive
+    takes the reference's three stdin answers (main.cpp:163-228)."""
+    n = 1500
+    _run([DRIVER, "--n", str(n), "--steps", "4", "--init", "libc", "--quiet", "--dump", str(tmp_path / "q")])
+    _run([DRIVER, "--n", str(n), "--steps", "4", "--init", "libc", "--quiet", "--sync-each-step", "--dump", str(tmp_path / "s")])
+    assert np.array_equal(_f4(tmp_path / "q.x.f4", n), _f4(tmp_path / "s.x.f4", n))
+    out = _run([DRIVER, "--n", str(n), "--init", "libc", "--interactive", "--dump", str(tmp_path / "i")], input="0\nn\n4\n")
+    assert json.loads(out.strip().splitlines()[-1])["steps"] == 4
+    assert np.array_equal(_f4(tmp_path / "q.x.f4", n), _f4(tmp_path / "i.x.f4", n))
+    r = subprocess.run([DRIVER, "--interactive"], input="1\n", capture_output=True, text=True)
+    assert r.returncode != 0 and "reduction" in r.stderr
+    # body 0 of the libc init is the reference's
+    x0 = _f4(tmp_path / "q.x.f4", n)
+    assert x0[0, 3] == np.float32(798460160.0)
+
+
+def test_headless_strict_kernel_matches_oracle(oracle, nb, tmp_path):
+    n = 777
+    _run([DRIVER, "--n", str(n), "--steps", "3", "--init", "ref", "--seed", "5", "--kernel", "strict", "--quiet", "--dump", str(tmp_path / "st")])
+    x0 = nb.engine.seeded_bodies(n, 0, 5)
+    xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
+    oracle.step_jacobi(xo, ao, vo, dt=0.1, eps2=0.002, steps=3)
+    assert np.array_equal(_f4(tmp_path / "st.x.f4", n), xo) and np.array_equal(_f4(tmp_path / "st.v.f4", n), vo)
+
+
+def test_compare_host_to_device_program():
+    """compareHostToDevice in the reference's own terms: lock-step GPU/CPU steps, then the 1 % rule on
+    positions, velocities and accelerations."""
+    out = _run([HARNESS, "--n", "1024", "--steps", "10"])
+    assert "Starting verification..." in out and "Verification complete" in out      # validation.cpp:83,87
+    r = json.loads(out.strip().splitlines()[-1])
+    assert r["bad_positions"] == 0 and r["cpu_order"] == "inplace"
+    out = _run([HARNESS, "--n", "1024", "--steps", "10", "--jacobi"])
+    r = json.loads(out.strip().splitlines()[-1])
+    assert r["bad_positions"] == 0 and r["bad_velocities"] <= 2 and r["bad_accelerations"] <= 2
