@@ -91,13 +91,20 @@ int nbody_ctx_destroy(nbody_ctx* ctx);
  * when the softening keeps 1/sqrt(d^3) finite. */
 int nbody_ctx_set_params(nbody_ctx* ctx, float dt, float eps2);
 
-/* kernel: NBODY_KERNEL_*; tile: LDS tile in bodies (0 = default 1024; the reference's
+/* kernel: NBODY_KERNEL_*; tile: LDS tile in bodies (0 = default 2048 at 4 bodies per lane, else 1024; the reference's
  * THREADS_PER_BLOCK*TILE_WIDTH_FACTOR, constants.h:11-12, is 32); bodies_per_lane: register
  * blocking (0 = default 4); jsplit: source-range slabs per launch (0 = auto from N). */
 int nbody_ctx_set_kernel(nbody_ctx* ctx, int kernel, int tile, int bodies_per_lane, int jsplit);
 
 /* Launch on this HIP stream (a hipStream_t passed as void*; NULL = the context's own stream). */
 int nbody_ctx_set_stream(nbody_ctx* ctx, void* hip_stream);
+
+/* nbody_step() can replay a captured hipGraph of 32 (force, integrate) pairs instead of 64 host
+ * launches. mode: 0 never (default), -1 auto (N <= 16384 and steps >= 32), 1 whenever steps >= 32.
+ * Results are identical either way (same kernels, same order). Measured on MI355X it is neutral:
+ * queued eager launches are not host-bound (17.4 vs 17.1 us/step at N=1024, 28.1 vs 27.2 at
+ * N=8192); the floor at small N is the dependent-kernel boundary, not the host. */
+int nbody_ctx_set_graph(nbody_ctx* ctx, int mode);
 
 /* Pre-size the slab workspace for up to n_targets bodies so later calls never allocate. */
 int nbody_ctx_reserve(nbody_ctx* ctx, int n_targets);
@@ -163,7 +170,7 @@ int nbody_ctx_timing_read(nbody_ctx* ctx, double* force_ms, int* launches);
 
 /* ---- diagnostics ------------------------------------------------------------------------- */
 const char* nbody_last_error(void);
-/* e.g. "nbody_hip 0.1 gfx950 fast=lds-packed bpl4 tile1024" */
+/* e.g. "nbody_hip 0.1 gfx950 fast=lds-packed(bpl4,tile2048,u8) ..." */
 const char* nbody_version(void);
 /* What the context resolved for a problem of n targets x m sources: slabs per launch, grid
  * blocks, LDS bytes per block. Any out pointer may be NULL. */

@@ -45,6 +45,7 @@ _SIGNATURES = {
     "nbody_ctx_set_kernel": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "nbody_ctx_set_stream": (C.c_int, [_p, _p]),
     "nbody_ctx_reserve": (C.c_int, [_p, C.c_int]),
+    "nbody_ctx_set_graph": (C.c_int, [_p, C.c_int]),
     "nbody_step": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int]),
     "nbody_accel_range": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "nbody_integrate_range": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int]),

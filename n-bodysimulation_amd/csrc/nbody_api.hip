@@ -43,6 +43,8 @@ int fail(int code, const char* fmt, ...)
     } while (0)
 
 constexpr int kMaxSplit = 32;
+constexpr int kGraphMaxN = 16384;  // below this a step is a few tens of microseconds: launch-bound
+constexpr int kGraphChunk = 32;    // steps per graph launch
 
 }  // namespace
 
@@ -62,6 +64,22 @@ struct nbody_ctx {
     bool timing = false;
     std::vector<hipEvent_t> events;  // start/stop pairs around force launches
     size_t events_used = 0;
+    // hipGraph of `graph_chunk` (force, integrate) pairs for launch-bound small systems, cached
+    // for one set of arguments
+    int use_graph = 0;   // -1 auto (n <= kGraphMaxN), 0 never (default: measured neutral, see nbody.h), 1 always
+    hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t graph = nullptr;
+    struct GraphKey {
+        const void *x, *a, *v, *slabs;
+        int n, bpl, tile, jsplit, kernel, chunk;
+        float dt, eps2;
+        hipStream_t stream;
+        bool operator==(const GraphKey& o) const
+        {
+            return x == o.x && a == o.a && v == o.v && slabs == o.slabs && n == o.n && bpl == o.bpl && tile == o.tile &&
+                   jsplit == o.jsplit && kernel == o.kernel && chunk == o.chunk && dt == o.dt && eps2 == o.eps2 && stream == o.stream;
+        }
+    } graph_key{};
 };
 
 namespace {
@@ -77,14 +95,17 @@ struct Shape {
 // Launch shape for (n_targets x n_sources). The reference hard-codes 32 threads/block and a
 // 32-body tile (constants.h:11-12); here the block is 256 threads, each lane holds `bpl`
 // targets, and the source range is cut into `jsplit` slabs so that the grid has at least
-// ~8 workgroups per CU (measured on MI355X: 4 slabs reach 99% of the 16-slab rate at
-// N=262144; more blocks mainly smooth the tail).
+// ~16 workgroups per CU (more, smaller workgroups mainly smooth the tail of the launch).
 Shape resolve_shape(const nbody_ctx* c, int n_targets, int n_sources)
 {
     Shape s{};
-    s.bpl = c->bpl ? c->bpl : (n_targets >= 32768 ? 4 : (n_targets >= 8192 ? 2 : 1));
-    s.tile = c->tile ? c->tile : 1024;
-    if (s.tile == 2048) s.bpl = 4;  // the 2048-body tile is only instantiated for 4 targets per lane
+    // small systems: fewer targets per lane and a smaller tile so that the grid still covers the
+    // chip (N=8192, the reference's N_BODIES: 32 x 16 = 512 workgroups instead of 16 x 4)
+    s.bpl = c->bpl ? c->bpl : (n_targets >= 32768 ? 4 : (n_targets >= 16384 ? 2 : 1));
+    if (c->tile == 2048) s.bpl = 4;  // the 2048-body tile is only instantiated for 4 targets per lane
+    // measured at N=262144 (bench.py, ms/step): tile 1024: 15.98/15.82/15.76 at 8/16/32 slabs;
+    // tile 2048: 15.61/15.48/15.55
+    s.tile = c->tile ? c->tile : (s.bpl == 4 ? 2048 : (s.bpl == 2 ? 512 : 256));
     s.blocks_x = (n_targets + nbk::kWG * s.bpl - 1) / (nbk::kWG * s.bpl);
     if (c->kernel == NBODY_KERNEL_STRICT) {
         s.bpl = 1;
@@ -96,7 +117,7 @@ Shape resolve_shape(const nbody_ctx* c, int n_targets, int n_sources)
     if (c->jsplit) {
         s.jsplit = c->jsplit;
     } else {
-        const int want = 8 * c->num_cu;
+        const int want = 16 * c->num_cu;
         int js = 1;
         while (s.blocks_x * js < want && js < kMaxSplit) js *= 2;
         // keep at least two tiles per slab
@@ -195,7 +216,7 @@ const char* nbody_last_error(void) { return g_err; }
 
 const char* nbody_version(void)
 {
-    return "nbody_hip 0.1 gfx950 fast=lds-packed(bpl4,tile1024,u8) strict=ieee-seq f64=lds";
+    return "nbody_hip 0.1 gfx950 fast=lds-packed(bpl4,tile2048,u8) strict=ieee-seq f64=lds";
 }
 
 int nbody_device_count(int* count)
@@ -247,6 +268,8 @@ int nbody_ctx_destroy(nbody_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->slabs) (void)hipFree(c->slabs);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+    if (c->graph) (void)hipGraphDestroy(c->graph);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return NBODY_OK;
@@ -418,11 +441,42 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
         q.slab_stride = n;
     }
     const int iblocks = (n + nbk::kWG - 1) / nbk::kWG;
-    for (int k = 0; k < steps; ++k) {
+    int k = 0;
+    const bool graphable = !c->timing && (c->use_graph == 1 || (c->use_graph < 0 && n <= kGraphMaxN));
+    if (graphable && steps >= kGraphChunk) {
+        // Launch-bound regime: replay a captured chain of kGraphChunk steps instead of 2*kGraphChunk
+        // host launches. The kernels and their order are exactly those of the loop below.
+        const nbody_ctx::GraphKey key{p.x, q.a, q.v, c->slabs, n, s.bpl, s.tile, s.jsplit, c->kernel, kGraphChunk, c->dt, c->eps2, c->stream};
+        if (!c->graph_exec || !(key == c->graph_key)) {
+            if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+            if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+            HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            int rc = NBODY_OK;
+            for (int g = 0; g < kGraphChunk && rc == NBODY_OK; ++g) {
+                rc = launch_force_untimed(c, s, p);
+                nbk::integrate<<<iblocks, nbk::kWG, 0, c->stream>>>(q);
+            }
+            hipError_t ce = hipStreamEndCapture(c->stream, &c->graph);
+            if (rc != NBODY_OK) return rc;
+            if (ce != hipSuccess) return fail(NBODY_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+            HIP_TRY(hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
+            c->graph_key = key;
+        }
+        for (; k + kGraphChunk <= steps; k += kGraphChunk) HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
+    }
+    for (; k < steps; ++k) {
         if (int rc = launch_force(c, s, p)) return rc;
         nbk::integrate<<<iblocks, nbk::kWG, 0, c->stream>>>(q);
     }
     HIP_TRY(hipGetLastError());
+    return NBODY_OK;
+}
+
+int nbody_ctx_set_graph(nbody_ctx* c, int mode)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (mode < -1 || mode > 1) return fail(NBODY_ERR_CONFIG, "graph mode must be -1 (auto), 0 (off) or 1 (on)");
+    c->use_graph = mode;
     return NBODY_OK;
 }
 

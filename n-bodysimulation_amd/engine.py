@@ -92,6 +92,10 @@ class Context:
         self._stream = stream  # keep it alive
         check(self._lib.nbody_ctx_set_stream(self._h, C.c_void_p(stream.cuda_stream) if stream is not None else None))
 
+    def set_graph(self, mode: int) -> None:
+        """hipGraph replay of 32-step chains in nbody_step: -1 auto (small N), 0 off, 1 on."""
+        check(self._lib.nbody_ctx_set_graph(self._h, mode))
+
     def reserve(self, n_targets: int) -> None:
         check(self._lib.nbody_ctx_reserve(self._h, n_targets))
 

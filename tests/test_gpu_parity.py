@@ -300,3 +300,27 @@ def test_f64_step_matches_oracle(nb, oracle):
     # and the fp32 fast path agrees with fp64 to fp32 accuracy (BASELINE configs[4]'s tolerance check)
     xf, _, af = _gpu_run(nb, x0.astype(np.float32), 3, 0.01, 0.002, nb.KERNEL_FAST)
     assert np.abs(xf - xo)[:, :3].max() <= 2e-6
+
+
+# ---- hipGraph replay of launch-bound steps ---------------------------------------------------------------
+
+@pytest.mark.parametrize("n,kernel", [(4096, "fast"), (1000, "fast"), (2048, "strict")])
+def test_graph_replay_is_identical_to_eager_launches(nb, n, kernel):
+    k = nb.KERNEL_FAST if kernel == "fast" else nb.KERNEL_STRICT
+    x0 = nb.engine.seeded_bodies(n, 1, 3)
+    out = []
+    for mode in (0, 1):
+        sim = nb.engine.Simulation(x0, dt=0.01, eps2=0.002, kernel=k)
+        sim.ctx.set_graph(mode)
+        sim.run(70)              # two 32-step graph launches + 6 eager steps when the graph is on
+        sim.run(40)              # cached graph reused
+        out.append(sim.state())
+    for p, q in zip(out[0], out[1]):
+        assert np.array_equal(p, q)
+
+
+def test_small_n_shapes_cover_the_chip(nb):
+    ctx = nb.engine.Context()
+    assert ctx.launch_info(8192, 8192)["blocks"] >= 512      # the reference's N_BODIES
+    assert ctx.launch_info(262144, 262144)["blocks"] >= 4096
+    assert ctx.launch_info(1, 1)["blocks"] == 1
