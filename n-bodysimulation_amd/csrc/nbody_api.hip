@@ -99,13 +99,28 @@ struct Shape {
 Shape resolve_shape(const nbody_ctx* c, int n_targets, int n_sources)
 {
     Shape s{};
-    // small systems: fewer targets per lane and a smaller tile so that the grid still covers the
-    // chip (N=8192, the reference's N_BODIES: 32 x 16 = 512 workgroups instead of 16 x 4)
-    s.bpl = c->bpl ? c->bpl : (n_targets >= 32768 ? 4 : (n_targets >= 16384 ? 2 : 1));
+    // (targets per lane, tile) candidates, largest first. Measured at N=262144 (bench.py, ms/step):
+    // tile 1024: 15.98/15.82/15.76 at 8/16/32 slabs; tile 2048: 15.61/15.48/15.55. Smaller systems
+    // take the first candidate that still yields >= 2 workgroups per CU with >= 2 tiles per slab
+    // (N=8192, the reference's N_BODIES, ends at 1 target per lane, 256-body tile: 512 workgroups).
+    static const int cand[][2] = {{4, 2048}, {4, 1024}, {4, 512}, {2, 512}, {2, 256}, {1, 256}};
+    s.bpl = c->bpl;
+    s.tile = c->tile;
     if (c->tile == 2048) s.bpl = 4;  // the 2048-body tile is only instantiated for 4 targets per lane
-    // measured at N=262144 (bench.py, ms/step): tile 1024: 15.98/15.82/15.76 at 8/16/32 slabs;
-    // tile 2048: 15.61/15.48/15.55
-    s.tile = c->tile ? c->tile : (s.bpl == 4 ? 2048 : (s.bpl == 2 ? 512 : 256));
+    if (!s.bpl || !s.tile) {
+        int pick = 5;
+        for (int k = 0; k < 6; ++k) {
+            if ((c->bpl && cand[k][0] != c->bpl) || (c->tile && cand[k][1] != c->tile)) continue;
+            pick = k;
+            const long bx = (n_targets + nbk::kWG * cand[k][0] - 1) / (nbk::kWG * cand[k][0]);
+            const long ntile = (n_sources + cand[k][1] - 1) / cand[k][1];
+            const long js = ntile / 2 < 1 ? 1 : (ntile / 2 > kMaxSplit ? kMaxSplit : ntile / 2);
+            if (bx * js >= 2L * c->num_cu) break;
+        }
+        if (!s.bpl) s.bpl = cand[pick][0];
+        if (!s.tile) s.tile = cand[pick][1];
+        if (s.bpl != 4 && s.tile == 2048) s.tile = 1024;
+    }
     s.blocks_x = (n_targets + nbk::kWG * s.bpl - 1) / (nbk::kWG * s.bpl);
     if (c->kernel == NBODY_KERNEL_STRICT) {
         s.bpl = 1;

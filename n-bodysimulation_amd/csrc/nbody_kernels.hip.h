@@ -51,7 +51,13 @@ struct MathScalar {
     static constexpr int BPL = BPL_;
     float x[BPL], y[BPL], z[BPL];
     float ax[BPL], ay[BPL], az[BPL];
+    float e2;  // eps2 held in a VGPR: a VALU op with an SGPR source issues at half rate on gfx950
 
+    __device__ __forceinline__ void set_eps2(const float eps2)
+    {
+        e2 = eps2;
+        asm volatile("" : "+v"(e2));
+    }
     __device__ __forceinline__ void set(int k, const float4 b)
     {
         x[k] = b.x; y[k] = b.y; z[k] = b.z;
@@ -59,19 +65,19 @@ struct MathScalar {
     }
     __device__ __forceinline__ float4 acc(int k) const { return make_float4(ax[k], ay[k], az[k], 0.0f); }
 
-    __device__ __forceinline__ void pair4(const float sx, const float sy, const float sz, const float sm, const float eps2)
+    __device__ __forceinline__ void pair4(const float sx, const float sy, const float sz, const float sm)
     {
-        pair(make_float4(sx, sy, sz, sm), eps2);
+        pair(make_float4(sx, sy, sz, sm));
     }
 
-    __device__ __forceinline__ void pair(const float4 bj, const float eps2)
+    __device__ __forceinline__ void pair(const float4 bj)
     {
 #pragma unroll
         for (int k = 0; k < BPL; ++k) {
             const float rx = bj.x - x[k];
             const float ry = bj.y - y[k];
             const float rz = bj.z - z[k];
-            float d = __builtin_fmaf(rx, rx, eps2);
+            float d = __builtin_fmaf(rx, rx, e2);
             d = __builtin_fmaf(ry, ry, d);
             d = __builtin_fmaf(rz, rz, d);
             const float inv = __builtin_amdgcn_rsqf(d);  // v_rsq_f32, 1 ulp
@@ -96,7 +102,13 @@ struct MathPacked {
     static constexpr int H = BPL / 2;
     f32x2 x[H], y[H], z[H];
     f32x2 ax[H], ay[H], az[H];
+    f32x2 e2;  // {eps2, eps2} in a VGPR pair
 
+    __device__ __forceinline__ void set_eps2(const float eps2)
+    {
+        e2 = (f32x2){eps2, eps2};
+        asm volatile("" : "+v"(e2));
+    }
     __device__ __forceinline__ void set(int k, const float4 b)
     {
         x[k >> 1][k & 1] = b.x; y[k >> 1][k & 1] = b.y; z[k >> 1][k & 1] = b.z;
@@ -107,15 +119,11 @@ struct MathPacked {
         return make_float4(ax[k >> 1][k & 1], ay[k >> 1][k & 1], az[k >> 1][k & 1], 0.0f);
     }
 
-    __device__ __forceinline__ void pair(const float4 bj, const float eps2)
-    {
-        pair4(bj.x, bj.y, bj.z, bj.w, eps2);
-    }
+    __device__ __forceinline__ void pair(const float4 bj) { pair4(bj.x, bj.y, bj.z, bj.w); }
 
-    __device__ __forceinline__ void pair4(const float sx, const float sy, const float sz, const float sm, const float eps2)
+    __device__ __forceinline__ void pair4(const float sx, const float sy, const float sz, const float sm)
     {
         const f32x2 bx = {sx, sx}, by = {sy, sy}, bz = {sz, sz}, bm = {sm, sm};
-        const f32x2 e2 = {eps2, eps2};
 #pragma unroll
         for (int k = 0; k < H; ++k) {
             const f32x2 rx = bx - x[k];
@@ -193,6 +201,7 @@ __global__ void __launch_bounds__(kWG, MINW) force_lds(const ForceParams p)
     const int tid = threadIdx.x;
     const int ibase = p.i0 + blockIdx.x * (kWG * M::BPL);
     M t;
+    t.set_eps2(p.eps2);
     load_targets(p, ibase, t);
 
     int ja, jb;
@@ -226,16 +235,16 @@ __global__ void __launch_bounds__(kWG, MINW) force_lds(const ForceParams p)
         if (jt + TILE < jb) fetch(jt + TILE);
 #pragma unroll UNROLL
         for (int jj = 0; jj < TILE; ++jj) {
-            if (LAYOUT == 0) t.pair(sh[buf][jj], p.eps2);
+            if (LAYOUT == 0) t.pair(sh[buf][jj]);
             if (LAYOUT == 1) {
                 const float4 s = sh[buf][jj];
-                t.pair4(s.x, s.y, s.w, s.z, p.eps2);
+                t.pair4(s.x, s.y, s.w, s.z);
             }
             if (LAYOUT == 2) {
                 f32x2 a = *reinterpret_cast<const f32x2*>(&sh_xy[buf * TILE + jj]);
                 f32x2 b = *reinterpret_cast<const f32x2*>(&sh_zm[buf * TILE + jj]);
                 asm volatile("" : "+v"(a), "+v"(b));  // keep each half in a 64-bit pair of its own
-                t.pair4(a.x, a.y, b.x, b.y, p.eps2);
+                t.pair4(a.x, a.y, b.x, b.y);
             }
         }
     }
@@ -250,6 +259,7 @@ __global__ void __launch_bounds__(kWG, MINW) force_sgpr(const ForceParams p)
 {
     const int ibase = p.i0 + blockIdx.x * (kWG * M::BPL);
     M t;
+    t.set_eps2(p.eps2);
     load_targets(p, ibase, t);
     int ja, jb;
     slab_range(p.j0, p.j1, UNROLL, gridDim.y, blockIdx.y, ja, jb);
@@ -257,9 +267,9 @@ __global__ void __launch_bounds__(kWG, MINW) force_sgpr(const ForceParams p)
     int j = ja;
     for (; j + UNROLL <= jb; j += UNROLL) {
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) t.pair(xs[j + u], p.eps2);
+        for (int u = 0; u < UNROLL; ++u) t.pair(xs[j + u]);
     }
-    for (; j < jb; ++j) t.pair(xs[j], p.eps2);
+    for (; j < jb; ++j) t.pair(xs[j]);
     store_targets(p, ibase, blockIdx.y, t);
 }
 

@@ -99,6 +99,7 @@ template <class M>
 __global__ void __launch_bounds__(256) mb_pair(float* out, int iters, float b, float c)
 {
     M t;
+    t.set_eps2(0.002f);
 #pragma unroll
     for (int k = 0; k < M::BPL; ++k)
         t.set(k, make_float4(threadIdx.x * 1e-2f + k, threadIdx.x * 2e-2f - k, k * 0.5f, 0.f));
@@ -106,7 +107,7 @@ __global__ void __launch_bounds__(256) mb_pair(float* out, int iters, float b, f
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            t.pair(bj, 0.002f);
+            t.pair(bj);
             bj.x += c;  // so the compiler cannot hoist the pair
         }
     }
