@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — body-pair interactions/s of the all-pairs step on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n BODIES]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--bodies B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -11,7 +11,7 @@ the half-kick/drift integrate (TestProject/kernel.cu:80-130 in the reference).
 Workload (BASELINE.json): N = 262144 bodies, fp32, 1 GPU (configs[2], the size the metric is quoted
 on). With G > 1 ranks the bodies are block-partitioned and positions all-gathered once per step
 (RCCL); the run is WEAK-scaled: N(G) = 262144 * sqrt(G) rounded to a multiple of 1024*G, so every
-GPU evaluates the same 6.87e10 pairs per step. `--n` overrides (e.g. --n 1048576 for configs[3]).
+GPU evaluates the same 6.87e10 pairs per step. `--bodies` overrides (e.g. --bodies 1048576 for configs[3]).
 
 Rank 0 prints ONE JSON line. `value` = N^2 * steps / wall time of the timed region (max over
 ranks), inputs resident in HBM before the region starts. `roofline` is the force kernel's
@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=0, help="bodies (default: weak-scaled from 262144)")
+    ap.add_argument("--bodies", dest="n", type=int, default=0, help="number of bodies (default: weak-scaled from 262144)")
     ap.add_argument("--dt", type=float, default=0.01)
     ap.add_argument("--eps2", type=float, default=0.002)
     ap.add_argument("--init", type=int, default=1, help="0 reference cube, 1 Plummer")
@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--bpl", type=int, default=0)
     ap.add_argument("--jsplit", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="collective backend for --gpus > 1: nccl (RCCL; default) or gloo "
+                    "(rehearsal of the multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     import torch
@@ -112,24 +114,31 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > ndev:
+        raise SystemExit(f"{world} ranks but {ndev} GPU(s): RCCL needs one GPU per rank (use --backend gloo to rehearse)")
+    dev = torch.device("cuda", local_rank % ndev)
+    torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     n = args.n or weak_n(world)
     x0 = nbody_amd.engine.seeded_bodies(n, args.init, 12345)
     kopts = dict(tile=args.tile, bodies_per_lane=args.bpl, jsplit=args.jsplit)
 
     if world == 1:
-        sim = nbody_amd.engine.Simulation(x0, dt=args.dt, eps2=args.eps2, device=local_rank, **kopts)
+        sim = nbody_amd.engine.Simulation(x0, dt=args.dt, eps2=args.eps2, device=dev.index, **kopts)
         ctx = sim.ctx
         run = lambda k: sim.run(k, sync=False)
         sync = ctx.sync
         info = ctx.launch_info(n, n)
         pairs_per_launch = float(n) * n
     else:
-        sim = nbody_amd.sharded.ShardedSimulation(x0, dt=args.dt, eps2=args.eps2, **kopts)
+        backend = nbody_amd.sharded.HipBackend(dev, args.dt, args.eps2, **kopts)
+        sim = nbody_amd.sharded.ShardedSimulation(x0, dt=args.dt, eps2=args.eps2, backend=backend)
         ctx = sim.backend.ctx
         run = sim.step
         sync = sim.sync
@@ -153,7 +162,7 @@ def main():
     ctx.timing(False)
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -165,7 +174,7 @@ def main():
     achieved = FLOP_PER_PAIR * rank_pairs / kernel_s / 1e12 if kernel_s > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    if world == 1 and n == BASE_N and os.path.exists(tpath):   # the PMC passes were taken on this workload only
         try:
             traffic = json.load(open(tpath)).get("force_kernel_hbm_bytes_per_launch")
         except Exception:
@@ -189,7 +198,7 @@ def main():
                         f"dt={args.dt}, eps2={args.eps2}",
             "n_bodies": n,
             "pairs_per_step": float(n) * n,
-            "partition": "single GPU" if world == 1 else f"{world} contiguous blocks of {sim.shard} bodies, RCCL all-gather of positions per step",
+            "partition": "single GPU" if world == 1 else f"{world} contiguous blocks of {sim.shard} bodies, {args.backend} all-gather of positions per step",
             "kernel": nbody_amd.load().nbody_version().decode(),
             "launch": info,
             "gflops_at_20_flop_per_pair": value * FLOP_PER_PAIR / 1e9,
