@@ -40,6 +40,10 @@ typedef struct nbody_float4 {
     float x, y, z, w;
 } nbody_float4;
 
+typedef struct nbody_float3 {
+    float x, y, z;
+} nbody_float3;
+
 typedef struct nbody_double4 {
     double x, y, z, w;
 } nbody_double4;
@@ -76,6 +80,16 @@ enum {
  * reconfigured through nbody_default_ctx(). N need not be a multiple of anything. */
 int nbody_simulate(nbody_float4* d_bodies, nbody_float4* d_accelerations, nbody_float4* d_velocity,
                    int n);
+
+/* The OLDER boundary of the reference's snapshot (Sim-Without-OpenGL-Integration/kernel.cuh:5,
+ * kernel.cu:85-125): `void simulate(float4* bodies, float3* accelerations, float3* velocity, int N)`
+ * with HOST pointers — every call copies the three arrays in, runs one step and copies bodies and
+ * velocity back; accelerations are not returned (the old kernel zeroes them, kernel.cu:78-80).
+ * DT = 0.01 and EPS2 = 0.002 are that snapshot's double literals (its constants.h:14-15), so the
+ * integrate is evaluated in double and rounded once per update. An adapter, not a fast path:
+ * it crosses PCIe five times per step by construction. */
+int nbody_simulate_host_legacy(nbody_float4* h_bodies, nbody_float3* h_accelerations,
+                               nbody_float3* h_velocity, int n);
 
 /* The context nbody_simulate() uses (created on first use, device 0). */
 int nbody_default_ctx(nbody_ctx** out);

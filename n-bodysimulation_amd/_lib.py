@@ -38,6 +38,7 @@ class NBodyError(RuntimeError):
 _p = C.c_void_p
 _SIGNATURES = {
     "nbody_simulate": (C.c_int, [_p, _p, _p, C.c_int]),
+    "nbody_simulate_host_legacy": (C.c_int, [_p, _p, _p, C.c_int]),
     "nbody_default_ctx": (C.c_int, [C.POINTER(_p)]),
     "nbody_ctx_create": (C.c_int, [C.POINTER(_p), C.c_int]),
     "nbody_ctx_destroy": (C.c_int, [_p]),

@@ -61,6 +61,9 @@ struct nbody_ctx {
     int num_cu = 256;
     void* slabs = nullptr;     // workspace: jsplit slabs of n_targets float4 (or double4)
     size_t slab_bytes = 0;
+    bool legacy_eps = false;     // strict kernel evaluates `+ EPS2` as the older snapshot does
+    void* legacy_buf = nullptr;  // device staging of the host-pointer adapter
+    size_t legacy_bytes = 0;
     bool timing = false;
     std::vector<hipEvent_t> events;  // start/stop pairs around force launches
     size_t events_used = 0;
@@ -190,7 +193,8 @@ int launch_force_untimed(nbody_ctx* c, const Shape& s, const nbk::ForceParams& p
 {
     if (p.i1 <= p.i0) return NBODY_OK;
     if (c->kernel == NBODY_KERNEL_STRICT) {
-        nbk::force_strict<1024><<<dim3(s.blocks_x), nbk::kWG, 0, c->stream>>>(p);
+        if (c->legacy_eps) nbk::force_strict<1024, true><<<dim3(s.blocks_x), nbk::kWG, 0, c->stream>>>(p);
+        else nbk::force_strict<1024, false><<<dim3(s.blocks_x), nbk::kWG, 0, c->stream>>>(p);
         HIP_TRY(hipGetLastError());
         return NBODY_OK;
     }
@@ -282,6 +286,7 @@ int nbody_ctx_destroy(nbody_ctx* c)
     if (!c) return NBODY_OK;
     (void)hipSetDevice(c->device);
     if (c->slabs) (void)hipFree(c->slabs);
+    if (c->legacy_buf) (void)hipFree(c->legacy_buf);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     if (c->graph) (void)hipGraphDestroy(c->graph);
@@ -533,6 +538,71 @@ int nbody_simulate(nbody_float4* d_bodies, nbody_float4* d_accelerations, nbody_
     if (int rc = nbody_default_ctx(&c)) return rc;
     if (int rc = nbody_step(c, d_bodies, d_accelerations, d_velocity, n, 1)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));  // simulate() is synchronous: kernel.cu:644
+    return NBODY_OK;
+}
+
+// The older snapshot's boundary (Sim-Without-OpenGL-Integration/kernel.cuh:5, kernel.cu:85-125): HOST
+// pointers, float3 velocity/acceleration, copy-in / launch / copy-out on every call, DT = 0.01 and
+// EPS2 = 0.002 compiled in as double literals. Device staging is kept in the default context
+// instead of being re-allocated (and leaked) per call as the original does (kernel.cu:94-96).
+int nbody_simulate_host_legacy(nbody_float4* h_bodies, nbody_float3* h_accelerations, nbody_float3* h_velocity, int n)
+{
+    nbody_ctx* c = nullptr;
+    if (int rc = nbody_default_ctx(&c)) return rc;
+    if (n < 0) return fail(NBODY_ERR_INVALID, "n=%d", n);
+    if (n == 0) return NBODY_OK;
+    if (!h_bodies || !h_accelerations || !h_velocity) return fail(NBODY_ERR_INVALID, "null host pointer");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t size4 = sizeof(float4) * (size_t)n, size3 = 3 * sizeof(float) * (size_t)n;
+    const size_t need = size4 + 2 * size3 + 64;
+    if (need > c->legacy_bytes) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->legacy_buf) HIP_TRY(hipFree(c->legacy_buf));
+        c->legacy_buf = nullptr;
+        c->legacy_bytes = 0;
+        HIP_TRY(hipMalloc(&c->legacy_buf, need));
+        c->legacy_bytes = need;
+    }
+    char* base = static_cast<char*>(c->legacy_buf);
+    float4* d_bodies = reinterpret_cast<float4*>(base);
+    float* d_vel = reinterpret_cast<float*>(base + size4);
+    float* d_acc = reinterpret_cast<float*>(base + size4 + ((size3 + 15) / 16) * 16);
+    HIP_TRY(hipMemcpyAsync(d_bodies, h_bodies, size4, hipMemcpyHostToDevice, c->stream));      // kernel.cu:99-101
+    HIP_TRY(hipMemcpyAsync(d_vel, h_velocity, size3, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_acc, h_accelerations, size3, hipMemcpyHostToDevice, c->stream));
+
+    const float saved_eps2 = c->eps2;
+    const bool saved_legacy = c->legacy_eps;
+    c->eps2 = 0.002f;
+    c->legacy_eps = true;
+    const Shape s = resolve_shape(c, n, n);
+    int rc = ensure_slabs(c, (size_t)s.jsplit * n * sizeof(float4));
+    if (rc == NBODY_OK) {
+        nbk::ForceParams p{};
+        p.x = d_bodies;
+        p.out = static_cast<float4*>(c->slabs);
+        p.i0 = 0; p.i1 = n; p.j0 = 0; p.j1 = n;
+        p.slab_stride = n;
+        p.accumulate = 0;
+        p.eps2 = c->eps2;
+        rc = launch_force(c, s, p);
+    }
+    c->eps2 = saved_eps2;
+    c->legacy_eps = saved_legacy;
+    if (rc != NBODY_OK) return rc;
+    nbk::IntegrateLegacyParams q{};
+    q.x = d_bodies;
+    q.v3 = d_vel;
+    q.a3 = d_acc;
+    q.slabs = static_cast<const float4*>(c->slabs);
+    q.nslab = s.jsplit;
+    q.slab_stride = n;
+    q.n = n;
+    nbk::integrate_legacy<<<(n + nbk::kWG - 1) / nbk::kWG, nbk::kWG, 0, c->stream>>>(q);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_bodies, d_bodies, size4, hipMemcpyDeviceToHost, c->stream));      // kernel.cu:115-124
+    HIP_TRY(hipMemcpyAsync(h_velocity, d_vel, size3, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return NBODY_OK;
 }
 

@@ -277,6 +277,10 @@ __global__ void __launch_bounds__(kWG, MINW) force_sgpr(const ForceParams p)
 // strict flavour — the reference's arithmetic, operation by operation
 // ---------------------------------------------------------------------------------------
 
+// LEGACY = the older snapshot's arithmetic (Sim-Without-OpenGL-Integration/kernel.cu:5-25 with its
+// constants.h:14 `#define EPS2 0.002`, a double literal): the float sum r.r is promoted to double
+// for the `+ EPS2`, then rounded back to float.
+template <bool LEGACY>
 __device__ __forceinline__ void pair_strict(const float4 bi, const float4 bj, float& ax, float& ay,
                                             float& az, const float eps2)
 {
@@ -285,7 +289,9 @@ __device__ __forceinline__ void pair_strict(const float4 bi, const float4 bj, fl
     const float rx = bj.x - bi.x;
     const float ry = bj.y - bi.y;
     const float rz = bj.z - bi.z;
-    const float d = rx * rx + ry * ry + rz * rz + eps2;
+    float d;
+    if (LEGACY) d = (float)((double)(rx * rx + ry * ry + rz * rz) + 0.002);
+    else d = rx * rx + ry * ry + rz * rz + eps2;
     const float denom = 1.0f / __builtin_sqrtf(d * d * d);  // correctly rounded sqrt and divide
     const float s = bj.w * denom;
     ax += rx * s;
@@ -294,7 +300,7 @@ __device__ __forceinline__ void pair_strict(const float4 bi, const float4 bj, fl
 }
 
 // One target per lane, sources in index order through one LDS tile. grid = ceil((i1-i0)/256).
-template <int TILE>
+template <int TILE, bool LEGACY = false>
 __global__ void __launch_bounds__(kWG) force_strict(const ForceParams p)
 {
 #pragma clang fp contract(off)
@@ -319,7 +325,8 @@ __global__ void __launch_bounds__(kWG) force_strict(const ForceParams p)
         __syncthreads();
         const int cnt = (p.j1 - jt < TILE) ? (p.j1 - jt) : TILE;
         for (int jj = 0; jj < cnt; ++jj) {
-            if (jt + jj != ic) pair_strict(bi, sh[jj], ax, ay, az, p.eps2);  // validation.cpp:35
+            // validation.cpp:35 skips j == i; the older GPU kernel does not (its term is an exact 0)
+            if (LEGACY || jt + jj != ic) pair_strict<LEGACY>(bi, sh[jj], ax, ay, az, p.eps2);
         }
     }
     if (i < p.i1) p.out[i - p.i0] = make_float4(ax, ay, az, 0.0f);
@@ -368,6 +375,42 @@ __global__ void __launch_bounds__(kWG) integrate(const IntegrateParams p)
     x.z += p.dt * v.z;
     p.v[i] = v;
     p.x[i] = x;  // .w (mass) carried through untouched
+}
+
+// The older snapshot's integrate (Sim-Without-OpenGL-Integration/kernel.cu:68-80): float3 velocity,
+// and `0.5 * DT` / `DT` with DT = 0.01 as DOUBLE literals, so each update is evaluated in double
+// and rounded to float once; the acceleration array is zeroed afterwards (kernel.cu:78-80).
+struct IntegrateLegacyParams {
+    float4* x;
+    float* v3;             // N packed float3
+    float* a3;             // N packed float3 (left zeroed, as the old kernel leaves it)
+    const float4* slabs;   // partial sums (nslab >= 1)
+    int nslab;
+    int slab_stride;
+    int n;
+};
+
+__global__ void __launch_bounds__(kWG) integrate_legacy(const IntegrateLegacyParams p)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * kWG + threadIdx.x;
+    if (i >= p.n) return;
+    float4 a = p.slabs[i];
+    for (int s = 1; s < p.nslab; ++s) {
+        const float4 q = p.slabs[(size_t)s * p.slab_stride + i];
+        a.x += q.x; a.y += q.y; a.z += q.z;
+    }
+    float vx = p.v3[3 * i + 0], vy = p.v3[3 * i + 1], vz = p.v3[3 * i + 2];
+    float4 x = p.x[i];
+    vx = (float)((double)vx + 0.5 * 0.01 * (double)a.x);
+    vy = (float)((double)vy + 0.5 * 0.01 * (double)a.y);
+    vz = (float)((double)vz + 0.5 * 0.01 * (double)a.z);
+    x.x = (float)((double)x.x + 0.01 * (double)vx);
+    x.y = (float)((double)x.y + 0.01 * (double)vy);
+    x.z = (float)((double)x.z + 0.01 * (double)vz);
+    p.v3[3 * i + 0] = vx; p.v3[3 * i + 1] = vy; p.v3[3 * i + 2] = vz;
+    p.a3[3 * i + 0] = 0.0f; p.a3[3 * i + 1] = 0.0f; p.a3[3 * i + 2] = 0.0f;
+    p.x[i] = x;
 }
 
 // out[i] = (accumulate ? out[i] : 0) + slabs[0][i] + slabs[1][i] + ... in slab order.

@@ -162,6 +162,18 @@ def simulate(d_bodies: torch.Tensor, d_accelerations: torch.Tensor, d_velocity: 
     check(_lib.load().nbody_simulate(_dptr(d_bodies), _dptr(d_accelerations), _dptr(d_velocity), n))
 
 
+def simulate_host_legacy(bodies: np.ndarray, accelerations3: np.ndarray, velocity3: np.ndarray) -> None:
+    """The older snapshot's ``simulate(float4* bodies, float3* accelerations, float3* velocity, int N)``
+    (Sim-Without-OpenGL-Integration/kernel.cuh:5): HOST arrays, updated in place (bodies, velocity);
+    one step with that snapshot's DT = 0.01 / EPS2 = 0.002 double literals."""
+    n = bodies.shape[0]
+    for arr, w in ((bodies, 4), (accelerations3, 3), (velocity3, 3)):
+        if not (arr.dtype == np.float32 and arr.shape == (n, w) and arr.flags.c_contiguous and arr.flags.writeable):
+            raise ValueError("expected contiguous writable float32 arrays of shape (n,4), (n,3), (n,3)")
+    check(_lib.load().nbody_simulate_host_legacy(C.c_void_p(bodies.ctypes.data), C.c_void_p(accelerations3.ctypes.data),
+                                                 C.c_void_p(velocity3.ctypes.data), n))
+
+
 class Simulation:
     """The headless run of main.cpp (alloc -> init -> H2D -> step loop), single GPU."""
 

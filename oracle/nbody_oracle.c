@@ -234,6 +234,37 @@ void oracle_step_jacobi_f64(odouble4 *X, odouble4 *A, odouble4 *V, int n, double
     }
 }
 
+/* The OLDER snapshot's step (Sim-Without-OpenGL-Integration/kernel.cu:5-25,38-82 with its
+ * constants.h:14-15, `EPS2 0.002` and `DT 0.01` as DOUBLE literals), in Jacobi order: the float sum
+ * r.r is promoted to double for `+ EPS2`; `gV + 0.5 * DT * a` and `gX + DT * gV` are evaluated in
+ * double and rounded to float once. The j == i pair is NOT skipped by that kernel (kernel.cu:30-34).
+ * V3 is N packed float3. */
+void oracle_step_legacy(ofloat4 *X, float *V3, int n)
+{
+    float *A = (float *)malloc(sizeof(float) * 3 * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; ++i) {
+        const ofloat4 bi = X[i];
+        float ax = 0.0f, ay = 0.0f, az = 0.0f;
+        for (int j = 0; j < n; ++j) {
+            const float rx = X[j].x - bi.x, ry = X[j].y - bi.y, rz = X[j].z - bi.z;
+            const float d = (float)((double)(rx * rx + ry * ry + rz * rz) + 0.002);
+            const float denom = 1.0f / sqrtf(d * d * d);
+            const float s = X[j].w * denom;
+            ax += rx * s; ay += ry * s; az += rz * s;
+        }
+        A[3 * i] = ax; A[3 * i + 1] = ay; A[3 * i + 2] = az;
+    }
+    for (int i = 0; i < n; ++i) {
+        V3[3 * i + 0] = (float)((double)V3[3 * i + 0] + 0.5 * 0.01 * (double)A[3 * i + 0]);
+        V3[3 * i + 1] = (float)((double)V3[3 * i + 1] + 0.5 * 0.01 * (double)A[3 * i + 1]);
+        V3[3 * i + 2] = (float)((double)V3[3 * i + 2] + 0.5 * 0.01 * (double)A[3 * i + 2]);
+        X[i].x = (float)((double)X[i].x + 0.01 * (double)V3[3 * i + 0]);
+        X[i].y = (float)((double)X[i].y + 0.01 * (double)V3[3 * i + 1]);
+        X[i].z = (float)((double)X[i].z + 0.01 * (double)V3[3 * i + 2]);
+    }
+    free(A);
+}
+
 /* utils.cpp:6 */
 static float oracle_random_float(float lo, float hi)
 {

@@ -51,6 +51,10 @@ void oracle_integrate(ofloat4 *X, ofloat4 *V, const ofloat4 *A, int n, float dt)
 /* All-double state (the build's own fp64 variant; no reference analogue). */
 void oracle_step_jacobi_f64(odouble4 *X, odouble4 *A, odouble4 *V, int n, double dt, double eps2);
 
+/* One step of the OLDER snapshot (Sim-Without-OpenGL-Integration/kernel.cu:5-82): float3 velocity,
+ * double-literal DT = 0.01 / EPS2 = 0.002, Jacobi order. V3 = N packed float3. */
+void oracle_step_legacy(ofloat4 *X, float *V3, int n);
+
 /* utils.cpp:6,30-37 (libc rand(), 4 draws per body x,y,z,w) and :19-27. */
 void oracle_fill_with_random4(ofloat4 *v, int n);
 void oracle_fill_with_zeroes4(ofloat4 *v, int n);

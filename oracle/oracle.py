@@ -52,6 +52,7 @@ def lib() -> C.CDLL:
         L.oracle_step_jacobi.argtypes = [p, p, p, C.c_int, C.c_float, C.c_float]
         L.oracle_step_jacobi_f64acc.argtypes = [p, p, p, C.c_int, C.c_float, C.c_float]
         L.oracle_step_jacobi_f64.argtypes = [p, p, p, C.c_int, C.c_double, C.c_double]
+        L.oracle_step_legacy.argtypes = [p, p, C.c_int]
         L.oracle_accel_range.argtypes = [p, p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
         L.oracle_integrate.argtypes = [p, p, p, C.c_int, C.c_float]
         L.oracle_fill_with_random4.argtypes = [p, C.c_int]
@@ -125,6 +126,14 @@ def step_jacobi_f64(X, A, V, dt, eps2, steps=1):
     _chk(X, np.float64), _chk(A, np.float64), _chk(V, np.float64)
     for _ in range(steps):
         lib().oracle_step_jacobi_f64(_ptr(X), _ptr(A), _ptr(V), len(X), float(dt), float(eps2))
+
+
+def step_legacy(X, V3, steps=1):
+    """The older snapshot's step (float3 velocity, double-literal DT=0.01/EPS2=0.002), Jacobi order."""
+    _chk(X)
+    assert V3.dtype == np.float32 and V3.shape == (len(X), 3) and V3.flags.c_contiguous
+    for _ in range(steps):
+        lib().oracle_step_legacy(_ptr(X), _ptr(V3), len(X))
 
 
 def accel_range(X, i0, i1, j0=0, j1=None, eps2=REF_EPS2, f64acc=False):

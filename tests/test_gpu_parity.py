@@ -324,3 +324,31 @@ def test_small_n_shapes_cover_the_chip(nb):
     assert ctx.launch_info(8192, 8192)["blocks"] >= 512      # the reference's N_BODIES
     assert ctx.launch_info(262144, 262144)["blocks"] >= 4096
     assert ctx.launch_info(1, 1)["blocks"] == 1
+
+
+# ---- the older host-pointer boundary ------------------------------------------------------
+
+def test_legacy_host_pointer_simulate(nb, oracle):
+    """simulate(float4* bodies, float3* acc, float3* vel, N) of the older snapshot: host arrays in/out,
+    float3 velocity, double-literal DT/EPS2 arithmetic. Strict kernel: bit-exact vs the restatement of
+    Sim-Without-OpenGL-Integration/kernel.cu:5-82 (Jacobi order); fast kernel: tolerance."""
+    import ctypes as C
+    n = 1500
+    x0 = nb.engine.seeded_bodies(n, 1, 8)
+    xo, vo = x0.copy(), np.zeros((n, 3), np.float32)
+    oracle.step_legacy(xo, vo, steps=3)
+    lib = nb.load()
+    ctx = C.c_void_p()
+    nb._lib.check(lib.nbody_default_ctx(C.byref(ctx)))
+    for kernel, exact in ((nb.KERNEL_STRICT, True), (nb.KERNEL_FAST, False)):
+        nb._lib.check(lib.nbody_ctx_set_kernel(ctx, kernel, 0, 0, 0))
+        x, a3, v3 = x0.copy(), np.full((n, 3), 5.0, np.float32), np.zeros((n, 3), np.float32)
+        for _ in range(3):
+            nb.engine.simulate_host_legacy(x, a3, v3)
+        if exact:
+            assert same_bits(x, xo) and np.array_equal(v3.view(np.uint32), vo.view(np.uint32))
+        else:
+            assert np.abs(x - xo)[:, :3].max() <= 1e-6 and np.abs(v3 - vo).max() <= 1e-5 * np.abs(vo).max() + 1e-7
+        assert np.all(a3 == 5.0)                     # accelerations are never copied back (kernel.cu:115-124)
+        assert np.array_equal(x[:, 3], x0[:, 3])
+    nb._lib.check(lib.nbody_ctx_set_kernel(ctx, nb.KERNEL_FAST, 0, 0, 0))
