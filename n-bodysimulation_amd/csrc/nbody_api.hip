@@ -98,7 +98,7 @@ struct Shape {
 // Launch shape for (n_targets x n_sources). The reference hard-codes 32 threads/block and a
 // 32-body tile (constants.h:11-12); here the block is 256 threads, each lane holds `bpl`
 // targets, and the source range is cut into `jsplit` slabs so that the grid has at least
-// ~16 workgroups per CU (more, smaller workgroups mainly smooth the tail of the launch).
+// ~64 workgroups per CU, up to 32 slabs (more, smaller workgroups smooth the tail of the launch: N=1048576 ran 268 ms/step with 4 slabs, 255 ms with 16).
 Shape resolve_shape(const nbody_ctx* c, int n_targets, int n_sources)
 {
     Shape s{};
@@ -135,7 +135,7 @@ Shape resolve_shape(const nbody_ctx* c, int n_targets, int n_sources)
     if (c->jsplit) {
         s.jsplit = c->jsplit;
     } else {
-        const int want = 16 * c->num_cu;
+        const int want = 64 * c->num_cu;
         int js = 1;
         while (s.blocks_x * js < want && js < kMaxSplit) js *= 2;
         // keep at least two tiles per slab
