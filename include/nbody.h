@@ -191,6 +191,12 @@ const char* nbody_version(void);
 int nbody_ctx_launch_info(nbody_ctx* ctx, int n_targets, int n_sources, int* jsplit, int* blocks,
                           int* lds_bytes);
 
+/* The same resolution without a context or a device (pure host logic, for tests and tooling):
+ * given the user's kernel/tile/bodies_per_lane/jsplit choices (0 = auto) and a CU count, what the
+ * launcher would pick. blocks_x = workgroups along the targets; the grid is blocks_x * jsplit. */
+int nbody_plan(int n_targets, int n_sources, int kernel, int tile, int bodies_per_lane, int jsplit,
+               int num_cu, int* out_bodies_per_lane, int* out_tile, int* out_jsplit, int* out_blocks_x);
+
 #ifdef __cplusplus
 }
 #endif

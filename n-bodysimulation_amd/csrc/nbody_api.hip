@@ -351,6 +351,25 @@ int nbody_ctx_reserve(nbody_ctx* c, int n_targets)
     return ensure_slabs(c, (size_t)kMaxSplit * (size_t)n_targets * sizeof(float4));
 }
 
+// Device-free view of the launch-shape logic (host tests; a context needs a GPU, this does not).
+int nbody_plan(int n_targets, int n_sources, int kernel, int tile, int bodies_per_lane, int jsplit, int num_cu,
+               int* out_bodies_per_lane, int* out_tile, int* out_jsplit, int* out_blocks_x)
+{
+    if (n_targets < 0 || n_sources < 0 || num_cu <= 0) return fail(NBODY_ERR_INVALID, "bad plan arguments");
+    nbody_ctx tmp;
+    tmp.kernel = kernel;
+    tmp.tile = tile;
+    tmp.bpl = bodies_per_lane;
+    tmp.jsplit = jsplit;
+    tmp.num_cu = num_cu;
+    const Shape s = resolve_shape(&tmp, n_targets, n_sources);
+    if (out_bodies_per_lane) *out_bodies_per_lane = s.bpl;
+    if (out_tile) *out_tile = s.tile;
+    if (out_jsplit) *out_jsplit = s.jsplit;
+    if (out_blocks_x) *out_blocks_x = s.blocks_x;
+    return NBODY_OK;
+}
+
 int nbody_ctx_launch_info(nbody_ctx* c, int n_targets, int n_sources, int* jsplit, int* blocks, int* lds_bytes)
 {
     if (int rc = check_ctx(c)) return rc;

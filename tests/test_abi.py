@@ -90,3 +90,46 @@ def test_zero_fill_and_types(nb):
     buf = np.ones((5, 4), np.float32)
     nb.load().nbody_fill_with_zeroes4(C.c_void_p(buf.ctypes.data), 5)
     assert np.all(buf == 0)
+
+
+def _plan(nb, nt, ns, kernel=0, tile=0, bpl=0, jsplit=0, cus=256):
+    o = [C.c_int() for _ in range(4)]
+    rc = nb.load().nbody_plan(nt, ns, kernel, tile, bpl, jsplit, cus, *[C.byref(x) for x in o])
+    assert rc == 0
+    return tuple(x.value for x in o)  # bpl, tile, jsplit, blocks_x
+
+
+def _slab_ranges(j0, j1, tile, nslab):
+    """Python mirror of nbk::slab_range (nbody_kernels.hip.h)."""
+    ntile = (j1 - j0 + tile - 1) // tile
+    per = (ntile + nslab - 1) // nslab
+    out = []
+    for s in range(nslab):
+        a = min(j0 + s * per * tile, j1)
+        b = min(a + per * tile, j1)
+        out.append((a, b))
+    return out
+
+
+def test_launch_plan_is_always_buildable_and_covers_every_source(nb):
+    """Host logic of the launcher, no GPU: every auto plan names an instantiated kernel, the grid
+    covers all targets, and the slabs tile [j0,j1) exactly once."""
+    built = {(1, 256), (1, 512), (1, 1024), (2, 256), (2, 512), (2, 1024), (4, 256), (4, 512), (4, 1024), (4, 2048)}
+    rng = np.random.default_rng(0)
+    sizes = [1, 2, 63, 64, 255, 256, 257, 1000, 1024, 4095, 8192, 16384, 32768, 65536, 100000, 262144, 1048576, 3000001]
+    sizes += [int(x) for x in rng.integers(1, 2_000_000, 60)]
+    for nt in sizes:
+        for ns in (nt, max(1, nt // 7), nt * 3 + 5):
+            for user in ({}, {"tile": 2048}, {"bpl": 1}, {"bpl": 2}, {"tile": 256}, {"jsplit": 5}, {"tile": 512, "bpl": 4}):
+                bpl, tile, js, bx = _plan(nb, nt, ns, **user)
+                assert (bpl, tile) in built, (nt, ns, user, bpl, tile)
+                assert 1 <= js <= 32 and bx * 256 * bpl >= nt > (bx - 1) * 256 * bpl
+                if "jsplit" in user:
+                    assert js == user["jsplit"]
+                r = _slab_ranges(0, ns, tile, js)
+                assert r[0][0] == 0 and r[-1][1] == ns
+                assert all(r[k][1] == r[k + 1][0] for k in range(js - 1)) and all(a <= b for a, b in r)
+    # strict: one target per lane, one slab, whatever the user asked
+    assert _plan(nb, 5000, 5000, kernel=1, tile=256, bpl=4, jsplit=8)[:3] == (1, 1024, 1)
+    # the sizes the docs quote
+    assert _plan(nb, 262144, 262144)[:2] == (4, 2048) and _plan(nb, 8192, 8192)[:2] == (1, 256)
