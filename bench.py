@@ -135,15 +135,13 @@ def main():
         run = lambda k: sim.run(k, sync=False)
         sync = ctx.sync
         info = ctx.launch_info(n, n)
-        pairs_per_launch = float(n) * n
     else:
         backend = nbody_amd.sharded.HipBackend(dev, args.dt, args.eps2, **kopts)
         sim = nbody_amd.sharded.ShardedSimulation(x0, dt=args.dt, eps2=args.eps2, backend=backend)
         ctx = sim.backend.ctx
         run = sim.step
         sync = sim.sync
-        info = ctx.launch_info(sim.shard, sim.shard)
-        pairs_per_launch = None  # several launches of different sizes per step: use the step total
+        info = ctx.launch_info(sim.shard, sim.shard)   # the local pass; the remote passes differ in source count
 
     def barrier():
         sync()
