@@ -38,6 +38,20 @@ from . import _lib
 from ._lib import KERNEL_FAST
 
 
+def morton_order(bodies: np.ndarray, bits: int = 10) -> np.ndarray:
+    """Permutation that sorts bodies along a 3-D Morton (Z-order) curve, so that a contiguous index
+    block is also a compact block of space (BASELINE.json's "spatially block-partitioned"). The
+    all-pairs cost does not depend on it; it only makes each rank's block a spatial one."""
+    xyz = np.asarray(bodies[:, :3], np.float64)
+    lo, hi = xyz.min(0), xyz.max(0)
+    q = ((xyz - lo) / np.where(hi > lo, hi - lo, 1.0) * ((1 << bits) - 1)).astype(np.uint64)
+    key = np.zeros(len(xyz), np.uint64)
+    for b in range(bits):
+        for axis in range(3):
+            key |= ((q[:, axis] >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b + axis)
+    return np.argsort(key, kind="stable")
+
+
 class HipBackend:
     """Force/integrate on the rank's GPU through libnbody_hip.so, with a compute stream (the
     context's launch stream) and a communication stream for the all-gather."""
@@ -95,10 +109,14 @@ class ShardedSimulation:
     """`steps` x (all-gather, local forces, remote forces, integrate) over the ranks of `group`."""
 
     def __init__(self, bodies: np.ndarray, dt: float = _lib.DEFAULT_DT, eps2: float = _lib.DEFAULT_EPS2,
-                 group=None, backend=None, kernel: int = KERNEL_FAST, **kernel_opts):
+                 group=None, backend=None, kernel: int = KERNEL_FAST, spatial_sort: bool = False, **kernel_opts):
         bodies = np.ascontiguousarray(bodies, np.float32)
         if bodies.ndim != 2 or bodies.shape[1] != 4:
             raise ValueError("bodies must be (n,4) float32 {x,y,z,mass}")
+        # optional one-off Morton sort: index blocks become spatial blocks; undone in gather_state()
+        self.perm = morton_order(bodies) if spatial_sort and len(bodies) else None
+        if self.perm is not None:
+            bodies = np.ascontiguousarray(bodies[self.perm])
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -158,4 +176,9 @@ class ShardedSimulation:
                 outs.append(torch.cat(parts))
         else:
             outs = [self.x, self.v, self.a]
-        return tuple(o.cpu().numpy()[: self.n] for o in outs)
+        res = tuple(o.cpu().numpy()[: self.n] for o in outs)
+        if self.perm is not None:       # back to the caller's body order
+            inv = np.empty_like(self.perm)
+            inv[self.perm] = np.arange(self.n)
+            res = tuple(r[inv] for r in res)
+        return res

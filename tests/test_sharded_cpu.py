@@ -75,7 +75,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, steps, q):
+def _worker(rank, world, port, n, steps, q, spatial=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -86,10 +86,11 @@ def _worker(rank, world, port, n, steps, q):
         O.set_threads(1)
         x0 = nbody_amd.engine.seeded_bodies(n, 0, 31)
         be = CheckerBackend(0.1, 0.002)
-        sim = nbody_amd.sharded.ShardedSimulation(x0, dt=0.1, eps2=0.002, backend=be)
+        sim = nbody_amd.sharded.ShardedSimulation(x0, dt=0.1, eps2=0.002, backend=be, spatial_sort=spatial)
+        own0 = sim.x.numpy()[sim.i0:min(sim.i1, n), :3].copy()
         sim.step(steps)
         x, v, a = sim.gather_state()
-        q.put((rank, x, v, a, be.log, sim.i0, sim.i1, sim.n_pad))
+        q.put((rank, x, v, a, be.log, sim.i0, sim.i1, sim.n_pad, own0))
     finally:
         dist.destroy_process_group()
 
@@ -114,7 +115,7 @@ def test_sharded_schedule_matches_single_rank(world, n):
     xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
     O.step_jacobi(xo, ao, vo, dt=0.1, eps2=0.002, steps=steps)
     amax = max(np.abs(ao[:, :3]).max(), 1e-30)
-    for rank, x, v, a, log, i0, i1, n_pad in res:
+    for rank, x, v, a, log, i0, i1, n_pad, _own in res:
         # every rank ends with the same full state, equal to the single-rank Jacobi step up to the
         # summation order (own block first, then the blocks before and after it)
         assert np.abs(x - xo)[:, :3].max() / 1e5 <= 1e-6
@@ -128,6 +129,35 @@ def test_sharded_schedule_matches_single_rank(world, n):
         assert kinds[first_gather + 1] == "accel" and log[first_gather + 1][3:5] == (i0, i1)   # local block while gathering
         assert kinds[first_gather + 2] == "wait"
         assert i1 - i0 == (n + world - 1) // world and n_pad == (i1 - i0) * world
+
+
+def test_spatial_sort_gives_spatial_blocks_and_same_answer():
+    """spatial_sort=True: each rank's index block is a compact region (Morton order), results come
+    back in the caller's order and agree with the unsorted run to summation-order tolerance."""
+    from oracle import oracle as O
+    import nbody_amd
+    world, n, steps = 2, 256, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, steps, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    x0 = nbody_amd.engine.seeded_bodies(n, 0, 31)
+    xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
+    O.step_jacobi(xo, ao, vo, dt=0.1, eps2=0.002, steps=steps)
+    whole = np.prod(x0[:, :3].max(0) - x0[:, :3].min(0))
+    for rank, x, v, a, log, i0, i1, n_pad, own0 in res:
+        assert np.abs(x - xo)[:, :3].max() / 1e5 <= 1e-6
+        assert np.abs(a - ao)[:, :3].max() / np.abs(ao[:, :3]).max() <= 1e-5
+        assert np.array_equal(x[:, 3], x0[:, 3])                    # caller's order restored
+        assert np.prod(own0.max(0) - own0.min(0)) <= 0.62 * whole    # a half-space block, not the whole cube
+    perm = nbody_amd.sharded.morton_order(x0)
+    assert sorted(perm.tolist()) == list(range(n))
 
 
 def test_sharded_refuses_cpu_without_backend():
