@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--bpl", type=int, default=0)
     ap.add_argument("--jsplit", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="f64 = the build's own double-precision variant "
+                    "(BASELINE configs[4]; single GPU only)")
     ap.add_argument("--backend", default="nccl", help="collective backend for --gpus > 1: nccl (RCCL; default) or gloo "
                     "(rehearsal of the multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -129,7 +131,29 @@ def main():
     x0 = nbody_amd.engine.seeded_bodies(n, args.init, 12345)
     kopts = dict(tile=args.tile, bodies_per_lane=args.bpl, jsplit=args.jsplit)
 
-    if world == 1:
+    f64 = args.dtype == "f64"
+    if f64 and world > 1:
+        raise SystemExit("--dtype f64 is a single-GPU variant")
+    if f64:
+        import numpy as np
+
+        class _F64Sim:   # same alloc/init/H2D sequence as engine.Simulation, double state
+            def __init__(self):
+                self.ctx = nbody_amd.engine.Context(device=dev.index, jsplit=args.jsplit)
+                self.x = torch.from_numpy(x0.astype(np.float64)).to(dev)
+                self.v = torch.zeros_like(self.x)
+                self.a = torch.zeros_like(self.x)
+                self.shard, self.n_pad = n, n
+
+            def run(self, k, sync=False):
+                self.ctx.step_f64(self.x, self.a, self.v, args.dt, args.eps2, k)
+
+        sim = _F64Sim()
+        ctx = sim.ctx
+        run = lambda k: sim.run(k)
+        sync = ctx.sync
+        info = {"jsplit": args.jsplit or "auto", "kernel": "nbk::force_f64<2,512>"}
+    elif world == 1:
         sim = nbody_amd.engine.Simulation(x0, dt=args.dt, eps2=args.eps2, device=dev.index, **kopts)
         ctx = sim.ctx
         run = lambda k: sim.run(k, sync=False)
@@ -169,10 +193,13 @@ def main():
     # roofline of the dominant kernel (force accumulation), from its own event time on this rank
     rank_pairs = float(sim.shard) * sim.n_pad * args.steps if world > 1 else pairs_total
     kernel_s = force_ms * 1e-3
+    if f64:   # the fp64 launches are not event-bracketed: the step is >99.9 % force kernel, use the wall time
+        kernel_s, launches, force_ms = elapsed, args.steps, elapsed * 1e3
     achieved = FLOP_PER_PAIR * rank_pairs / kernel_s / 1e12 if kernel_s > 0 else 0.0
+    peak = 78.6 if f64 else FP32_VECTOR_PEAK_TFLOPS
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if world == 1 and n == BASE_N and os.path.exists(tpath):   # the PMC passes were taken on this workload only
+    if world == 1 and n == BASE_N and not f64 and os.path.exists(tpath):   # the PMC passes were taken on this workload only
         try:
             traffic = json.load(open(tpath)).get("force_kernel_hbm_bytes_per_launch")
         except Exception:
@@ -189,10 +216,10 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": args.dtype,
         "data": "synthetic",
         "config": {
-            "workload": f"all-pairs gravity step, N={n} bodies, fp32, {'Plummer' if args.init == 1 else 'reference-cube'} init seed 12345, "
+            "workload": f"all-pairs gravity step, N={n} bodies, {'fp64' if f64 else 'fp32'}, {'Plummer' if args.init == 1 else 'reference-cube'} init seed 12345, "
                         f"dt={args.dt}, eps2={args.eps2}",
             "n_bodies": n,
             "pairs_per_step": float(n) * n,
@@ -204,19 +231,20 @@ def main():
         "roofline": {
             "bound": "valu",
             "achieved": achieved,
-            "peak": FP32_VECTOR_PEAK_TFLOPS,
+            "peak": peak,
             "unit": "TFLOP/s",
-            "frac": achieved / FP32_VECTOR_PEAK_TFLOPS,
+            "frac": achieved / peak,
             "traffic": traffic,
-            "kernel": "nbk::force_lds (fp32 packed)",
+            "kernel": "nbk::force_f64" if f64 else "nbk::force_lds (fp32 packed)",
             "kernel_ms_avg": force_ms / max(launches, 1),
             "kernel_launches": launches,
             "flop_per_pair": FLOP_PER_PAIR,
-            "note": "fp32 vector-ALU bound (no MFMA, HBM traffic is O(N) per step); peak = 157.3 TFLOP/s fp32 vector = fp32 MFMA peak",
+            "note": ("fp64 vector-ALU bound; peak = 78.6 TFLOP/s fp64 vector" if f64 else
+                     "fp32 vector-ALU bound (no MFMA, HBM traffic is O(N) per step); peak = 157.3 TFLOP/s fp32 vector = fp32 MFMA peak"),
         },
     }
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not f64:
             try:
                 line["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # the baseline must never take the GPU number down with it

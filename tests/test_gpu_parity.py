@@ -352,3 +352,52 @@ def test_legacy_host_pointer_simulate(nb, oracle):
         assert np.all(a3 == 5.0)                     # accelerations are never copied back (kernel.cu:115-124)
         assert np.array_equal(x[:, 3], x0[:, 3])
     nb._lib.check(lib.nbody_ctx_set_kernel(ctx, nb.KERNEL_FAST, 0, 0, 0))
+
+
+# ---- BASELINE.json sizes ------------------------------------------------------------------------------------
+
+def test_config2_n65536_k10_prefix_against_oracle_subset(nb, oracle):
+    """configs[1]: N=65536, dt=0.01. After 9 GPU steps take the positions; the 10th step's stored
+    accelerations must be the oracle's accelerations at those positions (4096 sampled targets against
+    all sources), and the 10th step's integrate must be the oracle's integrate, bit for bit."""
+    n = 65536
+    x0 = nb.engine.seeded_bodies(n, 1, 12345)
+    sim = nb.engine.Simulation(x0, dt=0.01, eps2=0.002)
+    sim.run(9)
+    x9, v9, _ = sim.state()
+    sim.run(1)
+    x10, v10, a10 = sim.state()
+    idx = [(0, 2048), (30000, 32048)]
+    for i0, i1 in idx:
+        truth = oracle.accel_range(x9, i0, i1, 0, n, eps2=0.002, f64acc=True)
+        assert np.abs(a10[i0:i1] - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 1e-5
+    xs, vs = x9.copy(), v9.copy()
+    oracle.integrate(xs, vs, a10, dt=0.01)          # same arithmetic as validation.cpp:43-49
+    assert same_bits(xs, x10) and same_bits(vs, v10)
+    assert np.isfinite(x10).all() and np.array_equal(x10[:, 3], x0[:, 3])
+
+
+def test_config3_n262144_properties(nb, oracle):
+    """configs[2]: N=262144 — sampled targets vs the CPU (1024 x 262144 pairs), momentum balance, exact
+    mass linearity, and run-to-run bitwise reproducibility (fixed-order slab sums, no atomics)."""
+    n = 262144
+    x0 = nb.engine.seeded_bodies(n, 1, 12345)
+    ctx = nb.engine.Context(dt=0.01)
+    x = torch.from_numpy(x0).cuda()
+    a = torch.zeros_like(x)
+    ctx.accel_range(x, a, 0, n, 0, n)
+    ctx.sync()
+    ag = a.cpu().numpy()
+    for i0 in (0, 200000):
+        truth = oracle.accel_range(x0, i0, i0 + 512, 0, n, eps2=0.002, f64acc=True)
+        assert np.abs(ag[i0:i0 + 512] - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 1e-5
+    m = x0[:, 3:4].astype(np.float64)
+    assert np.abs((m * ag[:, :3]).sum(0)).max() / (m * np.abs(ag[:, :3])).sum() < 1e-6
+    a2 = torch.zeros_like(x)
+    ctx.accel_range(x, a2, 0, n, 0, n)
+    ctx.sync()
+    assert torch.equal(a, a2)
+    xs = x0.copy(); xs[:, 3] *= 4
+    ctx.accel_range(torch.from_numpy(xs).cuda(), a2, 0, n, 0, n)
+    ctx.sync()
+    assert np.array_equal(a2.cpu().numpy()[:, :3], 4 * ag[:, :3])
