@@ -138,6 +138,12 @@ int nbody_step(nbody_ctx* ctx, nbody_float4* d_bodies, nbody_float4* d_accelerat
 int nbody_accel_range(nbody_ctx* ctx, const nbody_float4* d_bodies, nbody_float4* d_acc_out, int i0,
                       int i1, int j0, int j1, int accumulate);
 
+/* The same with a source run that may wrap around the end of the array: sources j0, j0+1, ...,
+ * j0+count-1, indices taken modulo n_total. One launch covers "every block except my own" for a rank
+ * of the sharded step (j0 = end of the own block, count = n_total - block). */
+int nbody_accel_wrapped(nbody_ctx* ctx, const nbody_float4* d_bodies, int n_total,
+                        nbody_float4* d_acc_out, int i0, int i1, int j0, int count, int accumulate);
+
 /* Integrate bodies [i0,i1): d_bodies is the whole array (indexed absolutely), d_velocity and
  * d_acc hold the i1-i0 own entries. Asynchronous. */
 int nbody_integrate_range(nbody_ctx* ctx, nbody_float4* d_bodies, nbody_float4* d_velocity,

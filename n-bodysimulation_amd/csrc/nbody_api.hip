@@ -42,7 +42,7 @@ int fail(int code, const char* fmt, ...)
                         __FILE__, __LINE__);                                                \
     } while (0)
 
-constexpr int kMaxSplit = 32;
+constexpr int kMaxSplit = 64;
 constexpr int kGraphMaxN = 16384;  // below this a step is a few tens of microseconds: launch-bound
 constexpr int kGraphChunk = 32;    // steps per graph launch
 
@@ -381,20 +381,20 @@ int nbody_ctx_launch_info(nbody_ctx* c, int n_targets, int n_sources, int* jspli
     return NBODY_OK;
 }
 
-int nbody_accel_range(nbody_ctx* c, const nbody_float4* d_bodies, nbody_float4* d_acc_out, int i0, int i1,
-                      int j0, int j1, int accumulate)
+namespace {
+
+// targets [i0,i1) x sources j0 .. j0+count-1 (indices taken modulo `wrap` when wrap > 0)
+int accel_impl(nbody_ctx* c, const nbody_float4* d_bodies, nbody_float4* d_acc_out, int i0, int i1, int j0, int j1,
+               int wrap, int accumulate)
 {
-    if (int rc = check_ctx(c)) return rc;
-    if (i0 < 0 || i1 < i0 || j0 < 0 || j1 < j0) return fail(NBODY_ERR_INVALID, "bad range i[%d,%d) j[%d,%d)", i0, i1, j0, j1);
     const int nt = i1 - i0;
-    if (nt == 0) return NBODY_OK;
-    if (!d_bodies || !d_acc_out) return fail(NBODY_ERR_INVALID, "null device pointer");
     HIP_TRY(hipSetDevice(c->device));
     const Shape s = resolve_shape(c, nt, j1 - j0);
     nbk::ForceParams p{};
     p.x = reinterpret_cast<const float4*>(d_bodies);
     p.i0 = i0; p.i1 = i1; p.j0 = j0; p.j1 = j1;
     p.eps2 = c->eps2;
+    p.wrap = wrap;
     if (s.jsplit == 1) {
         p.out = reinterpret_cast<float4*>(d_acc_out);
         p.slab_stride = 0;
@@ -420,6 +420,29 @@ int nbody_accel_range(nbody_ctx* c, const nbody_float4* d_bodies, nbody_float4* 
     nbk::reduce_slabs<<<(nt + nbk::kWG - 1) / nbk::kWG, nbk::kWG, 0, c->stream>>>(r);
     HIP_TRY(hipGetLastError());
     return NBODY_OK;
+}
+
+}  // namespace
+
+int nbody_accel_range(nbody_ctx* c, const nbody_float4* d_bodies, nbody_float4* d_acc_out, int i0, int i1,
+                      int j0, int j1, int accumulate)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (i0 < 0 || i1 < i0 || j0 < 0 || j1 < j0) return fail(NBODY_ERR_INVALID, "bad range i[%d,%d) j[%d,%d)", i0, i1, j0, j1);
+    if (i1 == i0) return NBODY_OK;
+    if (!d_bodies || !d_acc_out) return fail(NBODY_ERR_INVALID, "null device pointer");
+    return accel_impl(c, d_bodies, d_acc_out, i0, i1, j0, j1, 0, accumulate);
+}
+
+int nbody_accel_wrapped(nbody_ctx* c, const nbody_float4* d_bodies, int n_total, nbody_float4* d_acc_out, int i0, int i1,
+                        int j0, int count, int accumulate)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (n_total <= 0 || i0 < 0 || i1 < i0 || i1 > n_total || j0 < 0 || j0 >= n_total || count < 0 || count > n_total)
+        return fail(NBODY_ERR_INVALID, "bad wrapped range: n=%d i[%d,%d) j0=%d count=%d", n_total, i0, i1, j0, count);
+    if (i1 == i0) return NBODY_OK;
+    if (!d_bodies || !d_acc_out) return fail(NBODY_ERR_INVALID, "null device pointer");
+    return accel_impl(c, d_bodies, d_acc_out, i0, i1, j0, j0 + count, n_total, accumulate);
 }
 
 int nbody_integrate_range(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_velocity, const nbody_float4* d_acc,

@@ -36,6 +36,8 @@ struct ForceParams {
     int slab_stride;    // elements between slabs
     int accumulate;     // start each sum from the value already in `out`
     float eps2;
+    int wrap;           // 0, or the system size: source index j >= wrap means body j - wrap (a source
+                        // run that continues past the end of the array wraps around to body 0)
 };
 
 // ---------------------------------------------------------------------------------------
@@ -145,15 +147,16 @@ struct MathPacked {
     }
 };
 
-// Source range of slab s when [j0,j1) is cut into `nslab` runs of whole tiles.
+// Source range of slab s when [j0,j1) is cut into `nslab` runs of whole tiles whose lengths differ
+// by at most one tile (slab s gets tiles [s*ntile/nslab, (s+1)*ntile/nslab)).
 __device__ __forceinline__ void slab_range(int j0, int j1, int tile, int nslab, int s, int& a, int& b)
 {
-    const int ntile = (j1 - j0 + tile - 1) / tile;
-    const int per = (ntile + nslab - 1) / nslab;
-    a = j0 + s * per * tile;
-    b = a + per * tile;
-    if (a > j1) a = j1;
-    if (b > j1) b = j1;
+    const long ntile = (j1 - j0 + tile - 1) / tile;
+    const long ta = (long)s * ntile / nslab;
+    const long tb = (long)(s + 1) * ntile / nslab;
+    const long la = (long)j0 + ta * tile, lb = (long)j0 + tb * tile;
+    a = la > j1 ? j1 : (int)la;
+    b = lb > j1 ? j1 : (int)lb;
 }
 
 template <class M>
@@ -213,7 +216,8 @@ __global__ void __launch_bounds__(kWG, MINW) force_lds(const ForceParams p)
 #pragma unroll
         for (int l = 0; l < LPT; ++l) {
             const int j = jt + l * kWG + tid;
-            pre[l] = (j < jb) ? p.x[j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const int js = (p.wrap && j >= p.wrap) ? j - p.wrap : j;
+            pre[l] = (j < jb) ? p.x[js] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
     };
 
@@ -320,13 +324,16 @@ __global__ void __launch_bounds__(kWG) force_strict(const ForceParams p)
 #pragma unroll
         for (int l = 0; l < LPT; ++l) {
             const int j = jt + l * kWG + tid;
-            if (j < p.j1) sh[l * kWG + tid] = p.x[j];
+            const int js = (p.wrap && j >= p.wrap) ? j - p.wrap : j;
+            if (j < p.j1) sh[l * kWG + tid] = p.x[js];
         }
         __syncthreads();
         const int cnt = (p.j1 - jt < TILE) ? (p.j1 - jt) : TILE;
         for (int jj = 0; jj < cnt; ++jj) {
             // validation.cpp:35 skips j == i; the older GPU kernel does not (its term is an exact 0)
-            if (LEGACY || jt + jj != ic) pair_strict<LEGACY>(bi, sh[jj], ax, ay, az, p.eps2);
+            const int j = jt + jj;
+            const int js = (p.wrap && j >= p.wrap) ? j - p.wrap : j;
+            if (LEGACY || js != ic) pair_strict<LEGACY>(bi, sh[jj], ax, ay, az, p.eps2);
         }
     }
     if (i < p.i1) p.out[i - p.i0] = make_float4(ax, ay, az, 0.0f);

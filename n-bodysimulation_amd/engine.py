@@ -121,6 +121,13 @@ class Context:
             raise ValueError("range beyond the body array")
         check(self._lib.nbody_accel_range(self._h, _dptr(x), _dptr(a_out), i0, i1, j0, j1, 1 if accumulate else 0))
 
+    def accel_wrapped(self, x: torch.Tensor, a_out: torch.Tensor, i0: int, i1: int, j0: int, count: int,
+                      accumulate: bool = False) -> None:
+        """Sources j0 .. j0+count-1 modulo len(x): one launch for a source run that wraps around."""
+        _check_f4(x), _check_f4(a_out, i1 - i0)
+        check(self._lib.nbody_accel_wrapped(self._h, _dptr(x), x.shape[0], _dptr(a_out), i0, i1, j0, count,
+                                            1 if accumulate else 0))
+
     def integrate_range(self, x: torch.Tensor, v_own: torch.Tensor, a_own: torch.Tensor, i0: int, i1: int) -> None:
         _check_f4(x), _check_f4(v_own, i1 - i0), _check_f4(a_own, i1 - i0)
         if i1 > x.shape[0]:

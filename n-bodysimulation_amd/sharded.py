@@ -12,12 +12,11 @@ build's own decomposition:
       all_gather(X_full <- own block)            comm     (in place, S*16 B per rank)
       A  = forces(own targets, own sources)      compute  (overlaps the all-gather)
       wait(all_gather)
-      A += forces(own targets, sources before the block)
-      A += forces(own targets, sources after the block)
+      A += forces(own targets, all other blocks: sources i1, i1+1, ... wrapping around to i0-1)
       v += (dt/2) a ; x += dt v  (own block)     compute
       -> event for the next step's all-gather
 
-The remote passes of step n end before the integrate of step n (same stream), and the
+The remote pass of step n ends before the integrate of step n (same stream), and the
 all-gather of step n+1 waits on that integrate, so no second position buffer is needed.
 
 One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, over xGMI). All compute
@@ -74,6 +73,9 @@ class HipBackend:
 
     def accel_range(self, x, a_own, i0, i1, j0, j1, accumulate):
         self.ctx.accel_range(x, a_own, i0, i1, j0, j1, accumulate)
+
+    def accel_wrapped(self, x, a_own, i0, i1, j0, count, accumulate):
+        self.ctx.accel_wrapped(x, a_own, i0, i1, j0, count, accumulate)
 
     def integrate_range(self, x, v_own, a_own, i0, i1):
         self.ctx.integrate_range(x, v_own, a_own, i0, i1)
@@ -150,10 +152,9 @@ class ShardedSimulation:
             b.accel_range(self.x, self.a, self.i0, self.i1, self.i0, self.i1, False)
             if gather:
                 b.wait_gather()
-            if self.i0 > 0:
-                b.accel_range(self.x, self.a, self.i0, self.i1, 0, self.i0, True)
-            if self.i1 < self.n_pad:
-                b.accel_range(self.x, self.a, self.i0, self.i1, self.i1, self.n_pad, True)
+            if self.world > 1:
+                # every other rank's block in ONE launch: sources i1, i1+1, ... wrapping around to i0-1
+                b.accel_wrapped(self.x, self.a, self.i0, self.i1, self.i1 % self.n_pad, self.n_pad - self.shard, True)
             b.integrate_range(self.x, self.v, self.a, self.i0, self.i1)
             b.mark_integrated()
             self._fresh = False

@@ -102,11 +102,10 @@ def _plan(nb, nt, ns, kernel=0, tile=0, bpl=0, jsplit=0, cus=256):
 def _slab_ranges(j0, j1, tile, nslab):
     """Python mirror of nbk::slab_range (nbody_kernels.hip.h)."""
     ntile = (j1 - j0 + tile - 1) // tile
-    per = (ntile + nslab - 1) // nslab
     out = []
     for s in range(nslab):
-        a = min(j0 + s * per * tile, j1)
-        b = min(a + per * tile, j1)
+        a = min(j0 + (s * ntile // nslab) * tile, j1)
+        b = min(j0 + ((s + 1) * ntile // nslab) * tile, j1)
         out.append((a, b))
     return out
 
@@ -123,12 +122,14 @@ def test_launch_plan_is_always_buildable_and_covers_every_source(nb):
             for user in ({}, {"tile": 2048}, {"bpl": 1}, {"bpl": 2}, {"tile": 256}, {"jsplit": 5}, {"tile": 512, "bpl": 4}):
                 bpl, tile, js, bx = _plan(nb, nt, ns, **user)
                 assert (bpl, tile) in built, (nt, ns, user, bpl, tile)
-                assert 1 <= js <= 32 and bx * 256 * bpl >= nt > (bx - 1) * 256 * bpl
+                assert 1 <= js <= 64 and bx * 256 * bpl >= nt > (bx - 1) * 256 * bpl
                 if "jsplit" in user:
                     assert js == user["jsplit"]
                 r = _slab_ranges(0, ns, tile, js)
                 assert r[0][0] == 0 and r[-1][1] == ns
                 assert all(r[k][1] == r[k + 1][0] for k in range(js - 1)) and all(a <= b for a, b in r)
+                lens = [-(-(b - a) // tile) for a, b in r]
+                assert max(lens) - min(lens) <= 1                     # slabs balanced to within one tile
     # strict: one target per lane, one slab, whatever the user asked
     assert _plan(nb, 5000, 5000, kernel=1, tile=256, bpl=4, jsplit=8)[:3] == (1, 1024, 1)
     # the sizes the docs quote

@@ -401,3 +401,37 @@ def test_config3_n262144_properties(nb, oracle):
     ctx.accel_range(torch.from_numpy(xs).cuda(), a2, 0, n, 0, n)
     ctx.sync()
     assert np.array_equal(a2.cpu().numpy()[:, :3], 4 * ag[:, :3])
+
+
+@pytest.mark.parametrize("kernel", ["fast", "strict"])
+def test_accel_wrapped_source_run(nb, oracle, kernel):
+    """Sources j0 .. j0+count-1 modulo N in one launch (the remote pass of a rank): equals the sum
+    over the two plain ranges it wraps across; the strict kernel continues the running sum in that
+    exact order."""
+    n = 3000
+    x0 = nb.engine.seeded_bodies(n, 0, 41)
+    k = nb.KERNEL_FAST if kernel == "fast" else nb.KERNEL_STRICT
+    ctx = nb.engine.Context(kernel=k)
+    x = torch.from_numpy(x0).cuda()
+    for (i0, i1) in ((1000, 1750), (0, 750), (2250, 3000)):
+        a = torch.zeros((i1 - i0, 4), device="cuda")
+        ctx.accel_range(x, a, i0, i1, i0, i1, False)                       # own block first
+        ctx.accel_wrapped(x, a, i0, i1, i1 % n, n - (i1 - i0), True)       # then everybody else, wrapping
+        ctx.sync()
+        got = a.cpu().numpy()
+        if kernel == "strict":
+            want = oracle.accel_range(x0, i0, i1, i0, i1, eps2=0.002)
+            # continue the sequential sums in the wrapped order
+            for t, i in enumerate(range(i0, i1)):
+                acc = want[t].copy()
+                for jj in range(i1, i1 + n - (i1 - i0)):
+                    acc = oracle.pair(x0[i], x0[jj % n], acc, eps2=0.002)
+                want[t] = acc
+            assert same_bits(got, want)
+        else:
+            want = oracle.accel_range(x0, i0, i1, 0, n, eps2=0.002, f64acc=True)
+            assert np.abs(got - want)[:, :3].max() / np.abs(want[:, :3]).max() <= 1e-5
+    with pytest.raises(nb.NBodyError):
+        ctx.accel_wrapped(x, a, 0, 750, n, 10)            # j0 must lie inside the array
+    with pytest.raises(nb.NBodyError):
+        ctx.accel_wrapped(x, a, 0, 750, 5, n + 1)         # at most one lap

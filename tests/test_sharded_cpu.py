@@ -43,6 +43,19 @@ class CheckerBackend:
                     acc = self.O.pair(xn[i], xn[j], acc, eps2=self.eps2)
             an[t] = acc
 
+    def accel_wrapped(self, x, a_own, i0, i1, j0, count, accumulate):
+        self.log.append(("accel", i0, i1, j0, j0 + count, bool(accumulate)))
+        assert accumulate
+        xn, an = x.numpy(), a_own.numpy()
+        n = len(xn)
+        for t, i in enumerate(range(i0, i1)):
+            acc = an[t].copy()
+            for jj in range(j0, j0 + count):
+                j = jj % n
+                if j != i:
+                    acc = self.O.pair(xn[i], xn[j], acc, eps2=self.eps2)
+            an[t] = acc
+
     def integrate_range(self, x, v_own, a_own, i0, i1):
         self.log.append(("integrate", i0, i1))
         xs = x.numpy()[i0:i1].copy()
