@@ -10,8 +10,8 @@ the half-kick/drift integrate (TestProject/kernel.cu:80-130 in the reference).
 
 Workload (BASELINE.json): N = 262144 bodies, fp32, 1 GPU (configs[2], the size the metric is quoted
 on). With G > 1 ranks the bodies are block-partitioned and positions all-gathered once per step
-(RCCL); the run is WEAK-scaled: N(G) = 262144 * sqrt(G) rounded to a multiple of 1024*G, so every
-GPU evaluates the same 6.87e10 pairs per step. `--bodies` overrides (e.g. --bodies 1048576 for configs[3]).
+(RCCL); the run is WEAK-scaled: N(G) = 262144 * sqrt(G) rounded to a multiple of 8192*G (376832,
+524288, 720896 bodies at G = 2, 4, 8), so every GPU evaluates 6.9e10 (+-5 %) pairs per step. `--bodies` overrides (e.g. --bodies 1048576 for configs[3]).
 
 Rank 0 prints ONE JSON line. `value` = N^2 * steps / wall time of the timed region (max over
 ranks), inputs resident in HBM before the region starts. `roofline` is the force kernel's
@@ -39,7 +39,9 @@ BASE_N = 262144
 def weak_n(gpus: int) -> int:
     if gpus == 1:
         return BASE_N
-    q = 1024 * gpus
+    # every rank's block a multiple of 8192 bodies (8 target workgroups): shapes with an odd number of
+    # target workgroups run 2-4 % slower (tools/shape_probe.py), which would be a shape artefact, not scaling
+    q = 8192 * gpus
     return int(round(BASE_N * math.sqrt(gpus) / q)) * q
 
 
