@@ -108,6 +108,9 @@ def main():
     import torch
     import torch.distributed as dist
     import nbody_amd
+    if not os.path.exists(nbody_amd._lib.LIB_PATH) and int(os.environ.get("RANK", "0")) == 0:
+        import __graft_entry__            # un-built snapshot: compile the HIP library in-tree first
+        __graft_entry__.build()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
