@@ -87,3 +87,26 @@ def test_compare_host_to_device_program():
     out = _run([HARNESS, "--n", "1024", "--steps", "10", "--jacobi"])
     r = json.loads(out.strip().splitlines()[-1])
     assert r["bad_positions"] == 0 and r["bad_velocities"] <= 2 and r["bad_accelerations"] <= 2
+
+
+def test_source_level_dropin_with_reference_header_names(nb, tmp_path):
+    """tests/dropin_main.cpp is written against "constants.h", "kernel.cuh", "utils.h", "validation.h"
+    like the reference's main.cpp; it compiles with -Iinclude/compat, links libnbody_hip.so and agrees
+    with the Python host layer bit for bit (N_BODIES = 8192, libc-rand init, DT/EPS2 of constants.h)."""
+    exe = str(tmp_path / "dropin_main")
+    libdir = os.path.join(ROOT, "n-bodysimulation_amd")
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include", "compat"), "-o", exe,
+                        os.path.join(ROOT, "tests", "dropin_main.cpp"), "-L" + libdir, "-lnbody_hip", "-Wl,-rpath," + libdir],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = _run([exe, "4"])
+    assert "Starting the simulation..." in out and "Simulation complete" in out
+    last = out.strip().splitlines()[-1]
+    assert "N_BODIES=8192" in last and "DT=0.1" in last
+    import ctypes
+    ctypes.CDLL(None).srand(1)
+    sim = nb.engine.Simulation(nb.engine.libc_random_bodies(8192))
+    sim.run(4)
+    x, _, _ = sim.state()
+    body0 = [float(t) for t in last.split("body0=")[1].split()]
+    assert np.array_equal(np.array(body0, np.float32), x[0])
