@@ -135,7 +135,11 @@ Shape resolve_shape(const nbody_ctx* c, int n_targets, int n_sources)
     if (c->jsplit) {
         s.jsplit = c->jsplit;
     } else {
-        const int want = 64 * c->num_cu;
+        // ~16 workgroups per CU is enough when the number of target workgroups is a multiple of 8
+        // (N=262144: 15.5 ms/step at 16, 32 or 64 slabs). Shapes with an odd count are slower and want
+        // the finest split (92672 x 648704: 15.2 ms at 16 slabs, 14.2 ms at 64). Each slab costs
+        // 16 B/body of HBM write + read, so no more of them than needed.
+        const int want = (s.blocks_x % 8 == 0 ? 16 : 64) * c->num_cu;
         int js = 1;
         while (s.blocks_x * js < want && js < kMaxSplit) js *= 2;
         // keep at least two tiles per slab
