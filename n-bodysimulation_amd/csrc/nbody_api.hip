@@ -104,7 +104,7 @@ Shape resolve_shape(const nbody_ctx* c, int n_targets, int n_sources)
     Shape s{};
     // (targets per lane, tile) candidates, largest first. Measured at N=262144 (bench.py, ms/step):
     // tile 1024: 15.98/15.82/15.76 at 8/16/32 slabs; tile 2048: 15.61/15.48/15.55. Smaller systems
-    // take the first candidate that still yields >= 2 workgroups per CU with >= 2 tiles per slab
+    // take the first candidate that still yields >= 2 workgroups per CU
     // (N=8192, the reference's N_BODIES, ends at 1 target per lane, 256-body tile: 512 workgroups).
     static const int cand[][2] = {{4, 2048}, {4, 1024}, {4, 512}, {2, 512}, {2, 256}, {1, 256}};
     s.bpl = c->bpl;
@@ -142,9 +142,13 @@ Shape resolve_shape(const nbody_ctx* c, int n_targets, int n_sources)
         const int want = (s.blocks_x % 8 == 0 ? 16 : 64) * c->num_cu;
         int js = 1;
         while (s.blocks_x * js < want && js < kMaxSplit) js *= 2;
-        // keep at least two tiles per slab
+        // at least two tiles per slab (the second tile's loads overlap the first tile's arithmetic),
+        // except when the grid would leave CUs idle: then one-tile slabs (N=1024: 11 us/step with 4
+        // one-tile slabs, 17 us with 2 two-tile slabs)
         const int ntile = (n_sources + s.tile - 1) / s.tile;
-        while (js > 1 && ntile / js < 2) js /= 2;
+        int cap = ntile / 2 > 1 ? ntile / 2 : 1;
+        if ((long)s.blocks_x * cap < 2L * c->num_cu) cap = ntile > 1 ? ntile : 1;
+        if (js > cap) js = cap;
         s.jsplit = js;
     }
     if (s.jsplit < 1) s.jsplit = 1;
