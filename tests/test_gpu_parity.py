@@ -435,3 +435,25 @@ def test_accel_wrapped_source_run(nb, oracle, kernel):
         ctx.accel_wrapped(x, a, 0, 750, n, 10)            # j0 must lie inside the array
     with pytest.raises(nb.NBodyError):
         ctx.accel_wrapped(x, a, 0, 750, 5, n + 1)         # at most one lap
+
+
+def test_randomised_ranges_strict_bitwise(nb, oracle):
+    """40 random (N, target range, source range, accumulate chain) cases: the strict kernel through
+    nbody_accel_range / nbody_accel_wrapped equals the oracle's sequential sums bit for bit."""
+    rng = np.random.default_rng(99)
+    ctx = nb.engine.Context(kernel=nb.KERNEL_STRICT)
+    for case in range(40):
+        n = int(rng.integers(2, 2500))
+        x0 = _rand_bodies(n, 1000 + case, scale=10.0 ** rng.uniform(-2, 5), mlo=1e-3, mhi=1e9)
+        x = torch.from_numpy(x0).cuda()
+        i0 = int(rng.integers(0, n)); i1 = int(rng.integers(i0 + 1, n + 1))
+        cuts = sorted(int(c) for c in rng.integers(0, n + 1, 3))
+        a = torch.zeros((i1 - i0, 4), device="cuda")
+        want = np.zeros((i1 - i0, 4), np.float32)
+        first = True
+        for j0, j1 in ((0, cuts[0]), (cuts[0], cuts[1]), (cuts[1], cuts[2]), (cuts[2], n)):
+            ctx.accel_range(x, a, i0, i1, j0, j1, accumulate=not first)
+            first = False
+        ctx.sync()
+        want = oracle.accel_range(x0, i0, i1, 0, n, eps2=0.002)     # the same sources in the same order
+        assert same_bits(a.cpu().numpy(), want), (case, n, i0, i1, cuts)
