@@ -457,3 +457,24 @@ def test_randomised_ranges_strict_bitwise(nb, oracle):
         ctx.sync()
         want = oracle.accel_range(x0, i0, i1, 0, n, eps2=0.002)     # the same sources in the same order
         assert same_bits(a.cpu().numpy(), want), (case, n, i0, i1, cuts)
+
+
+def test_strict_kernel_on_hostile_inputs(nb, oracle):
+    """Extreme magnitudes (overflowing d*d*d, denormal products), coincident bodies, zero and negative
+    masses, moving bodies: strict kernel == Jacobi oracle bit for bit, NaN for NaN."""
+    rng = np.random.default_rng(31415)
+    for case in range(25):
+        n = int(rng.integers(1, 700))
+        mag = 10.0 ** rng.uniform(-18, 18)
+        x0 = (rng.normal(0, 1, (n, 4)) * mag).astype(np.float32)
+        x0[:, 3] = (rng.normal(0, 1, n) * 10.0 ** rng.uniform(-30, 12)).astype(np.float32)
+        if n > 3:
+            x0[1, :3] = x0[0, :3]
+            x0[2, 3] = 0.0
+        xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
+        with np.errstate(all="ignore"):
+            oracle.step_jacobi(xo, ao, vo, dt=0.1, eps2=0.002, steps=2)
+        x, v, a = _gpu_run(nb, x0, 2, 0.1, 0.002, nb.KERNEL_STRICT)
+        for p, q, nm in ((x, xo, "x"), (v, vo, "v"), (a, ao, "a")):
+            same = (bits(p) == bits(q)) | ((p == 0) & (q == 0)) | (np.isnan(p) & np.isnan(q))
+            assert same.all(), (case, n, mag, nm, int((~same).sum()))
