@@ -36,6 +36,19 @@ def test_one_rank_nccl_group_equals_single_gpu(nb):
         x, v, a = sim.state()
         assert np.abs(xs - x)[:, :3].max() <= 1e-6
         assert np.abs(as_ - a)[:, :3].max() / np.abs(a[:, :3]).max() <= 1e-5
+        # the RCCL calls of the multi-rank path, as far as one rank can exercise them: the in-place
+        # all_gather_into_tensor on the communication stream, the event hand-over, MAX all-reduce, barrier
+        before = sh.x.clone()
+        sh.backend.all_gather(sh.x, sh.i0, sh.i1, None)
+        sh.backend.wait_gather()
+        sh.sync()
+        assert torch.equal(sh.x, before)
+        t = torch.tensor([1.5], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        assert float(t.item()) == 1.5
+        sh.step(2)                       # and stepping still works after a gather
+        sh.sync()
     finally:
         dist.destroy_process_group()
 
