@@ -180,6 +180,8 @@ def main():
 
     run(args.warmup)
     barrier()
+    if world > 1:
+        backend.comm_timing = True
     ctx.timing(True)
     t0 = time.perf_counter()
     run(args.steps)
@@ -187,6 +189,7 @@ def main():
     elapsed = time.perf_counter() - t0
     force_ms, launches = ctx.timing_read()
     ctx.timing(False)
+    comm = backend.comm_report() if world > 1 else None
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
@@ -232,6 +235,7 @@ def main():
             "kernel": nbody_amd.load().nbody_version().decode(),
             "launch": info,
             "gflops_at_20_flop_per_pair": value * FLOP_PER_PAIR / 1e9,
+            **({"comm_rank0": comm} if comm else {}),
         },
         "roofline": {
             "bound": "valu",

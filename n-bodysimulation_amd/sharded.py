@@ -64,6 +64,10 @@ class HipBackend:
         self.ctx = Context(device=device.index, dt=dt, eps2=eps2, kernel=kernel, stream=self.compute, **kernel_opts)
         self._integrated = torch.cuda.Event()
         self._gathered = torch.cuda.Event()
+        # optional per-step communication timing (bench.py): events around the all-gather on the comm
+        # stream and after the own-block pass on the compute stream
+        self.comm_timing = False
+        self._comm_events = []   # (gather_start, gather_end, local_pass_end) per step
 
     def empty(self, n: int) -> torch.Tensor:
         return torch.zeros((n, 4), dtype=torch.float32, device=self.device)
@@ -86,6 +90,11 @@ class HipBackend:
         integrate that produced it."""
         self.comm.wait_event(self._integrated)
         with torch.cuda.stream(self.comm):
+            if self.comm_timing:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
+                      torch.cuda.Event(enable_timing=True))
+                self._comm_events.append(ev)
+                ev[0].record(self.comm)
             if dist.get_backend(group) == "nccl":
                 dist.all_gather_into_tensor(x_full, x_full[i0:i1], group=group)   # RCCL, in place
             else:
@@ -95,9 +104,24 @@ class HipBackend:
                 dist.all_gather(parts, x_full[i0:i1].clone(), group=group)
                 x_full.copy_(torch.cat(parts))
             self._gathered.record(self.comm)
+            if self.comm_timing:
+                self._comm_events[-1][1].record(self.comm)
 
     def wait_gather(self) -> None:
+        if self.comm_timing and self._comm_events:
+            self._comm_events[-1][2].record(self.compute)   # the own-block pass has been queued before this point
         self.compute.wait_event(self._gathered)
+
+    def comm_report(self) -> dict:
+        """Mean all-gather time and the part of it NOT hidden behind the own-block force pass."""
+        self.sync()
+        if not self._comm_events:
+            return {"steps": 0}
+        gather = [a.elapsed_time(b) for a, b, _ in self._comm_events]
+        exposed = [max(0.0, c.elapsed_time(b)) for _, b, c in self._comm_events]   # local pass end -> gather end
+        self._comm_events = []
+        return {"steps": len(gather), "all_gather_ms_avg": sum(gather) / len(gather),
+                "exposed_ms_avg": sum(exposed) / len(exposed)}
 
     def mark_integrated(self) -> None:
         self._integrated.record(self.compute)
