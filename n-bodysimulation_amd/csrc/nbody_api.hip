@@ -97,8 +97,9 @@ struct Shape {
 
 // Launch shape for (n_targets x n_sources). The reference hard-codes 32 threads/block and a
 // 32-body tile (constants.h:11-12); here the block is 256 threads, each lane holds `bpl`
-// targets, and the source range is cut into `jsplit` slabs so that the grid has at least
-// ~64 workgroups per CU, up to 32 slabs (more, smaller workgroups smooth the tail of the launch: N=1048576 ran 268 ms/step with 4 slabs, 255 ms with 16).
+// targets, and the source range is cut into `jsplit` slabs (at most 64) so that the grid has many
+// more workgroups than the chip has CUs: more, smaller workgroups smooth the tail of the launch
+// (N=1048576 ran 268 ms/step with 4 slabs, 255 ms with 16).
 Shape resolve_shape(const nbody_ctx* c, int n_targets, int n_sources)
 {
     Shape s{};
