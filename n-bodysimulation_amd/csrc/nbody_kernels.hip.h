@@ -15,7 +15,8 @@
 //     no float atomics).
 //
 // Two arithmetic flavours:
-//   fast   — d = fma chain, v_rsq_f32, f = m * rsq^3, fma accumulate (13 VALU ops / pair);
+//   fast   — packed across two targets: per two pairs 3 v_pk_add (r), 3 v_pk_fma (d = r.r + eps2),
+//            2 v_rsq_f32, 3 v_pk_mul (f = m * rsq^3), 3 v_pk_fma (a += r f);
 //   strict — the reference's operation order with individually rounded IEEE ops
 //            (1.0f / sqrtf(d*d*d), no contraction, j == i skipped as validation.cpp:35 does),
 //            one target per lane, sources in index order: bit-identical to the CPU
@@ -257,7 +258,8 @@ __global__ void __launch_bounds__(kWG, MINW) force_lds(const ForceParams p)
 
 // Same arithmetic, sources read straight from global memory at a wave-uniform address: the
 // compiler turns that into scalar loads (s_load_dwordx4..x16), so source bodies sit in SGPRs
-// and cost neither LDS traffic nor barriers. Kept as a measured alternative to force_lds.
+// and cost neither LDS traffic nor barriers. Kept as a measured alternative to force_lds (tools/kbench.hip
+// only: equal speed for packed maths, slower for scalar maths; it does not implement `wrap`).
 template <class M, int UNROLL, int MINW>
 __global__ void __launch_bounds__(kWG, MINW) force_sgpr(const ForceParams p)
 {
