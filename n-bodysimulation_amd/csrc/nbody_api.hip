@@ -105,8 +105,9 @@ Shape resolve_shape(const nbody_ctx* c, int n_targets, int n_sources)
     Shape s{};
     // (targets per lane, tile) candidates, largest first. Measured at N=262144 (bench.py, ms/step):
     // tile 1024: 15.98/15.82/15.76 at 8/16/32 slabs; tile 2048: 15.61/15.48/15.55. Smaller systems
-    // take the first candidate that still yields >= 2 workgroups per CU
-    // (N=8192, the reference's N_BODIES, ends at 1 target per lane, 256-body tile: 512 workgroups).
+    // take the first candidate whose grid can reach ~8 workgroups per CU (tools/kbench.hip sweeps at
+    // N = 4096 ... 32768: the number of workgroups is the lever, a slab of a single tile is fine once
+    // there are enough of them; N=8192, the reference's N_BODIES, ends at 1 target per lane, 256-body tile).
     static const int cand[][2] = {{4, 2048}, {4, 1024}, {4, 512}, {2, 512}, {2, 256}, {1, 256}};
     s.bpl = c->bpl;
     s.tile = c->tile;
@@ -118,8 +119,8 @@ Shape resolve_shape(const nbody_ctx* c, int n_targets, int n_sources)
             pick = k;
             const long bx = (n_targets + nbk::kWG * cand[k][0] - 1) / (nbk::kWG * cand[k][0]);
             const long ntile = (n_sources + cand[k][1] - 1) / cand[k][1];
-            const long js = ntile / 2 < 1 ? 1 : (ntile / 2 > kMaxSplit ? kMaxSplit : ntile / 2);
-            if (bx * js >= 2L * c->num_cu) break;
+            const long js = ntile < 1 ? 1 : (ntile > kMaxSplit ? kMaxSplit : ntile);
+            if (bx * js >= 8L * c->num_cu) break;
         }
         if (!s.bpl) s.bpl = cand[pick][0];
         if (!s.tile) s.tile = cand[pick][1];
@@ -143,13 +144,11 @@ Shape resolve_shape(const nbody_ctx* c, int n_targets, int n_sources)
         const int want = (s.blocks_x % 8 == 0 ? 16 : 64) * c->num_cu;
         int js = 1;
         while (s.blocks_x * js < want && js < kMaxSplit) js *= 2;
-        // at least two tiles per slab (the second tile's loads overlap the first tile's arithmetic),
-        // except when the grid would leave CUs idle: then one-tile slabs (N=1024: 11 us/step with 4
-        // one-tile slabs, 17 us with 2 two-tile slabs)
+        // never more slabs than tiles; small systems stop at 32 (every slab is one more 16 B/body read
+        // in the integrate, which is no longer negligible next to a sub-100-us force kernel)
         const int ntile = (n_sources + s.tile - 1) / s.tile;
-        int cap = ntile / 2 > 1 ? ntile / 2 : 1;
-        if ((long)s.blocks_x * cap < 2L * c->num_cu) cap = ntile > 1 ? ntile : 1;
-        if (js > cap) js = cap;
+        if (js > ntile) js = ntile > 0 ? ntile : 1;
+        if (n_targets < 65536 && js > 32) js = 32;
         s.jsplit = js;
     }
     if (s.jsplit < 1) s.jsplit = 1;

@@ -160,24 +160,24 @@ __device__ __forceinline__ void slab_range(int j0, int j1, int tile, int nslab, 
     b = lb > j1 ? j1 : (int)lb;
 }
 
-template <class M>
+template <class M, int WG = kWG>
 __device__ __forceinline__ void load_targets(const ForceParams& p, int ibase, M& t)
 {
 #pragma unroll
     for (int k = 0; k < M::BPL; ++k) {
-        int i = ibase + k * kWG + (int)threadIdx.x;
+        int i = ibase + k * WG + (int)threadIdx.x;
         if (i > p.i1 - 1) i = p.i1 - 1;  // clamp: the surplus lanes compute a copy, never store
         t.set(k, p.x[i]);
     }
 }
 
-template <class M>
+template <class M, int WG = kWG>
 __device__ __forceinline__ void store_targets(const ForceParams& p, int ibase, int slab, const M& t)
 {
     float4* out = p.out + (size_t)slab * p.slab_stride;
 #pragma unroll
     for (int k = 0; k < M::BPL; ++k) {
-        const int i = ibase + k * kWG + (int)threadIdx.x;
+        const int i = ibase + k * WG + (int)threadIdx.x;
         if (i < p.i1) {
             float4 a = t.acc(k);
             if (p.accumulate) {
@@ -193,20 +193,21 @@ __device__ __forceinline__ void store_targets(const ForceParams& p, int ibase, i
 // LAYOUT of a source in the LDS tile: 0 = {x,y,z,m} (one ds_read_b128), 1 = {x,y,m,z},
 // 2 = two 8-byte halves {x,y} | {z,m} in separate arrays. Same arithmetic; they differ only in
 // how many v_mov / s_nop hipcc adds around the op_sel broadcasts (measured in tools/kbench.hip).
-template <class M, int TILE, int UNROLL, int MINW, int LAYOUT = 0>
-__global__ void __launch_bounds__(kWG, MINW) force_lds(const ForceParams p)
+// WG = threads per workgroup (256 by default; 64 or 128 give small systems more, shorter workgroups).
+template <class M, int TILE, int UNROLL, int MINW, int LAYOUT = 0, int WG = kWG>
+__global__ void __launch_bounds__(WG, MINW) force_lds(const ForceParams p)
 {
-    static_assert(TILE % kWG == 0, "tile must be a multiple of the workgroup");
-    constexpr int LPT = TILE / kWG;  // float4 loads per thread per tile
+    static_assert(TILE % WG == 0, "tile must be a multiple of the workgroup");
+    constexpr int LPT = TILE / WG;  // float4 loads per thread per tile
     __shared__ float4 sh[2][TILE];
     float2* const sh_xy = reinterpret_cast<float2*>(&sh[0][0]);             // LAYOUT 2: [2][TILE] halves
     float2* const sh_zm = reinterpret_cast<float2*>(&sh[0][0]) + 2 * TILE;
 
     const int tid = threadIdx.x;
-    const int ibase = p.i0 + blockIdx.x * (kWG * M::BPL);
+    const int ibase = p.i0 + blockIdx.x * (WG * M::BPL);
     M t;
     t.set_eps2(p.eps2);
-    load_targets(p, ibase, t);
+    load_targets<M, WG>(p, ibase, t);
 
     int ja, jb;
     slab_range(p.j0, p.j1, TILE, gridDim.y, blockIdx.y, ja, jb);
@@ -216,7 +217,7 @@ __global__ void __launch_bounds__(kWG, MINW) force_lds(const ForceParams p)
     auto fetch = [&](int jt) {
 #pragma unroll
         for (int l = 0; l < LPT; ++l) {
-            const int j = jt + l * kWG + tid;
+            const int j = jt + l * WG + tid;
             const int js = (p.wrap && j >= p.wrap) ? j - p.wrap : j;
             pre[l] = (j < jb) ? p.x[js] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
@@ -227,7 +228,7 @@ __global__ void __launch_bounds__(kWG, MINW) force_lds(const ForceParams p)
     for (int jt = ja; jt < jb; jt += TILE, buf ^= 1) {
 #pragma unroll
         for (int l = 0; l < LPT; ++l) {
-            const int e = l * kWG + tid;
+            const int e = l * WG + tid;
             if (LAYOUT == 0) sh[buf][e] = pre[l];
             if (LAYOUT == 1) sh[buf][e] = make_float4(pre[l].x, pre[l].y, pre[l].w, pre[l].z);
             if (LAYOUT == 2) {
@@ -253,7 +254,7 @@ __global__ void __launch_bounds__(kWG, MINW) force_lds(const ForceParams p)
             }
         }
     }
-    store_targets(p, ibase, blockIdx.y, t);
+    store_targets<M, WG>(p, ibase, blockIdx.y, t);
 }
 
 // Same arithmetic, sources read straight from global memory at a wave-uniform address: the

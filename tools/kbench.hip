@@ -117,8 +117,11 @@ __global__ void __launch_bounds__(256) mb_pair(float* out, int iters, float b, f
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
-static float time_ms(const std::function<void()>& f, int reps = 5)
+static int g_inner = 1;  // launches per timed sample (small kernels: amortise the launch latency)
+static float time_ms(const std::function<void()>& f0, int reps = 5)
 {
+    const int inner = g_inner;
+    auto f = [&] { for (int q = 0; q < inner; ++q) f0(); };
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
@@ -137,23 +140,23 @@ static float time_ms(const std::function<void()>& f, int reps = 5)
     std::sort(ts.begin(), ts.end());
     CK(hipEventDestroy(e0));
     CK(hipEventDestroy(e1));
-    return ts[ts.size() / 2];
+    return ts[ts.size() / 2] / inner;
 }
 
 struct Variant {
     std::string name;
-    int bpl;
+    double bpl;
     std::function<void(const nbk::ForceParams&, int nslab)> launch;
 };
 
-template <class M, int TILE, int UNROLL, int MINW, int LAYOUT = 0>
+template <class M, int TILE, int UNROLL, int MINW, int LAYOUT = 0, int WG = 256>
 static Variant v_lds(const char* mname)
 {
     char nm[64];
-    snprintf(nm, sizeof nm, "lds%d %s bpl%d tile%-4d u%-2d w%d", LAYOUT, mname, M::BPL, TILE, UNROLL, MINW);
-    return {nm, M::BPL, [](const nbk::ForceParams& p, int nslab) {
-                dim3 g((p.i1 - p.i0 + 256 * M::BPL - 1) / (256 * M::BPL), nslab);
-                nbk::force_lds<M, TILE, UNROLL, MINW, LAYOUT><<<g, 256>>>(p);
+    snprintf(nm, sizeof nm, "lds%d %s bpl%d tile%-4d u%-2d wg%d", LAYOUT, mname, M::BPL, TILE, UNROLL, WG);
+    return {nm, M::BPL * WG / 256, [](const nbk::ForceParams& p, int nslab) {
+                dim3 g((p.i1 - p.i0 + WG * M::BPL - 1) / (WG * M::BPL), nslab);
+                nbk::force_lds<M, TILE, UNROLL, MINW, LAYOUT, WG><<<g, WG>>>(p);
             }};
 }
 template <class M, int UNROLL, int MINW>
@@ -173,6 +176,7 @@ int main(int argc, char** argv)
 {
     int n = argc > 1 ? atoi(argv[1]) : 65536;
     int do_mb = argc > 2 ? atoi(argv[2]) : 1;
+    g_inner = n <= 32768 ? 50 : 1;
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     printf("device %s  CUs %d  clock %d kHz  arch %s\n", prop.name, prop.multiProcessorCount,
@@ -218,7 +222,7 @@ int main(int argc, char** argv)
         hx[i] = make_float4(u() * 2e5f - 1e5f, u() * 2e5f - 1e5f, u() * 2e5f - 1e5f, 1e5f + u() * (1e9f - 1e5f));
     }
     float4 *dx, *dout, *dref;
-    const int max_slab = 32;
+    const int max_slab = 64;
     CK(hipMalloc(&dx, sizeof(float4) * n));
     CK(hipMalloc(&dout, sizeof(float4) * (size_t)n * max_slab));
     CK(hipMalloc(&dref, sizeof(float4) * n));
@@ -236,23 +240,20 @@ int main(int argc, char** argv)
            (double)n * n / (ms_strict * 1e-3));
 
     std::vector<Variant> vs = {
-        v_lds<P4, 1024, 8, 1, 0>("P"), v_lds<P4, 1024, 8, 1, 1>("P"), v_lds<P4, 1024, 8, 1, 2>("P"),
-        v_lds<P4, 2048, 8, 1, 0>("P"), v_lds<P4, 2048, 8, 1, 1>("P"), v_lds<P4, 2048, 8, 1, 2>("P"),
-        v_lds<P4, 512, 8, 1, 0>("P"),  v_lds<P4, 512, 8, 1, 1>("P"),  v_lds<P4, 512, 8, 1, 2>("P"),
-        v_lds<P4, 1024, 4, 1, 1>("P"), v_lds<P4, 1024, 16, 1, 1>("P"), v_lds<P4, 1024, 8, 2, 1>("P"),
-        v_lds<P8, 1024, 8, 1, 0>("P"), v_lds<P8, 1024, 8, 1, 1>("P"), v_lds<P8, 1024, 4, 1, 1>("P"),
-        v_lds<P2, 1024, 8, 1, 0>("P"), v_lds<P2, 1024, 8, 1, 1>("P"), v_lds<P2, 1024, 16, 1, 1>("P"),
-        v_sgpr<P4, 4, 1>("P"),        v_sgpr<P2, 8, 1>("P"),
+        v_lds<S1, 256, 8, 1, 0, 256>("S"), v_lds<P2, 256, 8, 1, 0, 256>("P"), v_lds<P2, 512, 8, 1, 0, 256>("P"), v_lds<P4, 512, 8, 1, 0, 256>("P"),
+        v_lds<P2, 256, 8, 1, 0, 128>("P"), v_lds<P2, 128, 8, 1, 0, 128>("P"), v_lds<P4, 256, 8, 1, 0, 128>("P"), v_lds<P4, 512, 8, 1, 0, 128>("P"),
+        v_lds<P2, 256, 8, 1, 0, 64>("P"),  v_lds<P2, 128, 8, 1, 0, 64>("P"),  v_lds<P2, 64, 8, 1, 0, 64>("P"),   v_lds<P4, 256, 8, 1, 0, 64>("P"),
+        v_lds<P4, 128, 8, 1, 0, 64>("P"),  v_lds<P4, 512, 8, 1, 0, 64>("P"),  v_lds<S1, 128, 8, 1, 0, 64>("S"),  v_lds<P8, 256, 8, 1, 0, 64>("P"),
     };
     p.out = dout;
     printf("%-34s %5s %9s %12s %8s %10s\n", "variant", "slabs", "ms", "pairs/s", "%peak20", "max rel err");
     double amax = 0;
     for (int i = 0; i < n; ++i) amax = std::max({amax, (double)fabsf(href[i].x), (double)fabsf(href[i].y), (double)fabsf(href[i].z)});
     for (auto& v : vs) {
-        for (int nslab : {4, 8, 16, 32}) {
+        for (int nslab : {1, 2, 4, 8, 16, 32, 64}) {
             // keep roughly 2..16 waves per SIMD worth of work
-            double waves = (double)n / (64.0 * v.bpl) * nslab;
-            if (waves < 1024 * 1.5 || waves > 1024 * 33) continue;
+            double waves = (double)n / (64.0 * v.bpl) * nslab;   // v.bpl here = targets per 256 lanes
+            if (waves < 1024 * 1.0 || waves > 1024 * 40) continue;
             float ms = time_ms([&] { v.launch(p, nslab); }, 3);
             CK(hipMemcpy(hout.data(), dout, sizeof(float4) * (size_t)n * nslab, hipMemcpyDeviceToHost));
             double err = 0;
