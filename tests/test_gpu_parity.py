@@ -478,3 +478,34 @@ def test_strict_kernel_on_hostile_inputs(nb, oracle):
         for p, q, nm in ((x, xo, "x"), (v, vo, "v"), (a, ao, "a")):
             same = (bits(p) == bits(q)) | ((p == 0) & (q == 0)) | (np.isnan(p) & np.isnan(q))
             assert same.all(), (case, n, mag, nm, int((~same).sum()))
+
+
+def test_config4_size_n1048576_on_one_gpu(nb, oracle):
+    """configs[3]'s size (N=1048576) as one rank-less launch: sampled targets against the CPU over all
+    1M sources, momentum balance, and the wrapped-run form a rank of the 8-GPU run would issue."""
+    n = 1048576
+    x0 = nb.engine.seeded_bodies(n, 1, 4242)
+    ctx = nb.engine.Context(dt=0.01)
+    x = torch.from_numpy(x0).cuda()
+    a = torch.zeros_like(x)
+    ctx.accel_range(x, a, 0, n, 0, n)
+    ctx.sync()
+    ag = a.cpu().numpy()
+    assert np.isfinite(ag).all()
+    for i0 in (0, 777000):
+        truth = oracle.accel_range(x0, i0, i0 + 256, 0, n, eps2=0.002, f64acc=True)
+        assert np.abs(ag[i0:i0 + 256] - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 2e-5
+    m = x0[:, 3:4].astype(np.float64)
+    assert np.abs((m * ag[:, :3]).sum(0)).max() / (m * np.abs(ag[:, :3])).sum() < 1e-6
+    # rank 3 of 8: own block, then everybody else through one wrapped launch
+    S = n // 8
+    i0, i1 = 3 * S, 4 * S
+    ar = torch.zeros((S, 4), device="cuda")
+    ctx.accel_range(x, ar, i0, i1, i0, i1, False)
+    ctx.accel_wrapped(x, ar, i0, i1, i1, n - S, True)
+    ctx.sync()
+    arn = ar.cpu().numpy()
+    # two different fp32 summation orders over 1M terms each: both within 2e-5 of the truth, 4e-5 of each other
+    assert np.abs(arn - ag[i0:i1])[:, :3].max() / np.abs(ag[:, :3]).max() <= 4e-5
+    truth = oracle.accel_range(x0, i0, i0 + 256, 0, n, eps2=0.002, f64acc=True)
+    assert np.abs(arn[:256] - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 2e-5
