@@ -281,6 +281,283 @@ __global__ void __launch_bounds__(kWG, MINW) force_sgpr(const ForceParams p)
 }
 
 // ---------------------------------------------------------------------------------------
+// symmetric flavour — every unordered pair of bodies evaluated ONCE (Newton's third law)
+// ---------------------------------------------------------------------------------------
+//
+// The system is cut into blocks of B = 64*W*BPL bodies. One workgroup (W wave64) takes one block
+// pair (I < J): wave w keeps 64*BPL bodies of block I in registers (BPL per lane) with their
+// accumulators, and block J passes through the wave 64 bodies at a time, ONE BODY PER LANE, also in
+// registers: {x,y,z,m} plus that body's own accumulator. Lane l meets the J-body of lane l+s of its
+// 16-lane row through a DPP row rotation (row_ror:s, s = 0..15, folded into the consuming
+// instruction or one v_mov_dpp per component); after 16 rotations the seven registers of the J-body
+// move on by one row (ds_bpermute, 4 times per 64 bodies). Per evaluated pair: r = xj - xi, d = r.r +
+// eps2, w = rsq(d)^3, a_i += (m_j w) r, t += (m_i w) r — 16 FMA-class ops + 1 v_rsq_f32 for TWO
+// counted interactions (the one-sided kernel needs 12 + 1 for one) — and per J-body and step three
+// v_add_dpp that carry t back to the body's home lane. No LDS and no barrier inside the pair loop.
+// The J-side sums of the W waves meet in LDS: in round q wave w works on chunk (q + w) mod (B/64),
+// so no two waves hold the same chunk in the same round; one barrier per round.
+// Output: slab[J][i in I] (I-side sums, from registers) and slab[I][j in J] (J-side sums, from LDS);
+// the diagonal tasks (I == I, one-sided arithmetic, same rotation scheme) write slab[I][i in I]. Every
+// slab element is written exactly once per launch and the integrate kernel adds the nb slabs in
+// index order: deterministic, no float atomics.
+
+struct SymParams {
+    const float4* x;   // bodies {x,y,z,mass}
+    float4* slabs;     // nb slabs, `stride` float4 apart
+    int n;             // bodies
+    int nb;            // blocks: ceil(n / B)
+    int stride;
+    float eps2;
+};
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(const float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// value of the lane S places away in the 16-lane row (row_ror); ror<S> and ror<(16-S)%16> are inverse
+template <int S>
+__device__ __forceinline__ float ror(const float v)
+{
+    if constexpr (S == 0) return v;
+    else return dpp_mov<0x120 + S>(v);
+}
+
+// Packed arithmetic for the rotation kernel: BPL stationary bodies per lane, two per register pair.
+template <int BPL_>
+struct SymPacked {
+    static_assert(BPL_ % 2 == 0, "packed maths handles bodies two at a time");
+    static constexpr int BPL = BPL_;
+    static constexpr int H = BPL / 2;
+    f32x2 x[H], y[H], z[H], m[H];
+    f32x2 ax[H], ay[H], az[H];
+    f32x2 e2;
+
+    __device__ __forceinline__ void set_eps2(const float eps2)
+    {
+        e2 = (f32x2){eps2, eps2};
+        asm volatile("" : "+v"(e2));
+    }
+    __device__ __forceinline__ void set(int k, const float4 b)
+    {
+        x[k >> 1][k & 1] = b.x; y[k >> 1][k & 1] = b.y; z[k >> 1][k & 1] = b.z; m[k >> 1][k & 1] = b.w;
+        ax[k >> 1][k & 1] = 0.0f; ay[k >> 1][k & 1] = 0.0f; az[k >> 1][k & 1] = 0.0f;
+    }
+    __device__ __forceinline__ float4 acc(int k) const
+    {
+        return make_float4(ax[k >> 1][k & 1], ay[k >> 1][k & 1], az[k >> 1][k & 1], 0.0f);
+    }
+    // all BPL stationary bodies against the moving body s; t = sum_k (m_k w_k) r_k when SYM
+    template <bool SYM>
+    __device__ __forceinline__ void pairs(const float sx, const float sy, const float sz, const float sm, float& tx,
+                                          float& ty, float& tz)
+    {
+        const f32x2 bx = {sx, sx}, by = {sy, sy}, bz = {sz, sz}, bm = {sm, sm};
+        f32x2 ux = {0.0f, 0.0f}, uy = {0.0f, 0.0f}, uz = {0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            const f32x2 rx = bx - x[k];
+            const f32x2 ry = by - y[k];
+            const f32x2 rz = bz - z[k];
+            f32x2 d = __builtin_elementwise_fma(rx, rx, e2);
+            d = __builtin_elementwise_fma(ry, ry, d);
+            d = __builtin_elementwise_fma(rz, rz, d);
+            f32x2 inv;
+            inv.x = __builtin_amdgcn_rsqf(d.x);
+            inv.y = __builtin_amdgcn_rsqf(d.y);
+            const f32x2 w = inv * inv * inv;
+            const f32x2 fi = bm * w;
+            ax[k] = __builtin_elementwise_fma(rx, fi, ax[k]);
+            ay[k] = __builtin_elementwise_fma(ry, fi, ay[k]);
+            az[k] = __builtin_elementwise_fma(rz, fi, az[k]);
+            if (SYM) {
+                const f32x2 fj = m[k] * w;
+                if (k == 0) { ux = rx * fj; uy = ry * fj; uz = rz * fj; }
+                else {
+                    ux = __builtin_elementwise_fma(rx, fj, ux);
+                    uy = __builtin_elementwise_fma(ry, fj, uy);
+                    uz = __builtin_elementwise_fma(rz, fj, uz);
+                }
+            }
+        }
+        tx = ux.x + ux.y; ty = uy.x + uy.y; tz = uz.x + uz.y;
+    }
+};
+
+// Scalar arithmetic for the rotation kernel: the row rotation can fold into v_sub_f32_dpp / v_mul_f32_dpp.
+template <int BPL_>
+struct SymScalar {
+    static constexpr int BPL = BPL_;
+    float x[BPL], y[BPL], z[BPL], m[BPL];
+    float ax[BPL], ay[BPL], az[BPL];
+    float e2;
+
+    __device__ __forceinline__ void set_eps2(const float eps2)
+    {
+        e2 = eps2;
+        asm volatile("" : "+v"(e2));
+    }
+    __device__ __forceinline__ void set(int k, const float4 b)
+    {
+        x[k] = b.x; y[k] = b.y; z[k] = b.z; m[k] = b.w;
+        ax[k] = 0.0f; ay[k] = 0.0f; az[k] = 0.0f;
+    }
+    __device__ __forceinline__ float4 acc(int k) const { return make_float4(ax[k], ay[k], az[k], 0.0f); }
+    template <bool SYM>
+    __device__ __forceinline__ void pairs(const float sx, const float sy, const float sz, const float sm, float& tx,
+                                          float& ty, float& tz)
+    {
+        tx = 0.0f; ty = 0.0f; tz = 0.0f;
+#pragma unroll
+        for (int k = 0; k < BPL; ++k) {
+            const float rx = sx - x[k];
+            const float ry = sy - y[k];
+            const float rz = sz - z[k];
+            float d = __builtin_fmaf(rx, rx, e2);
+            d = __builtin_fmaf(ry, ry, d);
+            d = __builtin_fmaf(rz, rz, d);
+            const float inv = __builtin_amdgcn_rsqf(d);
+            const float w = inv * inv * inv;
+            const float fi = sm * w;
+            ax[k] = __builtin_fmaf(rx, fi, ax[k]);
+            ay[k] = __builtin_fmaf(ry, fi, ay[k]);
+            az[k] = __builtin_fmaf(rz, fi, az[k]);
+            if (SYM) {
+                const float fj = m[k] * w;
+                if (k == 0) { tx = rx * fj; ty = ry * fj; tz = rz * fj; }
+                else {
+                    tx = __builtin_fmaf(rx, fj, tx);
+                    ty = __builtin_fmaf(ry, fj, ty);
+                    tz = __builtin_fmaf(rz, fj, tz);
+                }
+            }
+        }
+    }
+};
+
+template <int S, bool SYM, class M>
+__device__ __forceinline__ void sym_step(M& t, const float4& bj, float4& aj)
+{
+    float tx, ty, tz;
+    t.template pairs<SYM>(ror<S>(bj.x), ror<S>(bj.y), ror<S>(bj.z), ror<S>(bj.w), tx, ty, tz);
+    if (SYM) {  // a_j = -sum_i (m_i w) r, delivered to the moving body's lane
+        aj.x -= ror<(16 - S) % 16>(tx);
+        aj.y -= ror<(16 - S) % 16>(ty);
+        aj.z -= ror<(16 - S) % 16>(tz);
+    }
+}
+
+template <bool SYM, class M>
+__device__ __forceinline__ void sym_row_pass(M& t, const float4& bj, float4& aj)
+{
+    sym_step<0, SYM>(t, bj, aj);  sym_step<1, SYM>(t, bj, aj);  sym_step<2, SYM>(t, bj, aj);  sym_step<3, SYM>(t, bj, aj);
+    sym_step<4, SYM>(t, bj, aj);  sym_step<5, SYM>(t, bj, aj);  sym_step<6, SYM>(t, bj, aj);  sym_step<7, SYM>(t, bj, aj);
+    sym_step<8, SYM>(t, bj, aj);  sym_step<9, SYM>(t, bj, aj);  sym_step<10, SYM>(t, bj, aj); sym_step<11, SYM>(t, bj, aj);
+    sym_step<12, SYM>(t, bj, aj); sym_step<13, SYM>(t, bj, aj); sym_step<14, SYM>(t, bj, aj); sym_step<15, SYM>(t, bj, aj);
+}
+
+__device__ __forceinline__ float next_row(const float v, const int addr)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
+}
+
+// first index of row I in the row-major list of block pairs (I < J): I*(2nb - I - 1)/2
+__device__ __forceinline__ int sym_row_offset(int I, int nb) { return (int)(((long)I * (2L * nb - I - 1)) / 2); }
+
+// grid = nb*(nb-1)/2 pair tasks followed by nb diagonal tasks; block = 64*W threads.
+template <class M, int W>
+__global__ void __launch_bounds__(64 * W) force_sym(const SymParams p)
+{
+    constexpr int BPL = M::BPL;
+    constexpr int B = 64 * W * BPL;
+    constexpr int NCH = B / 64;
+    __shared__ float4 sh[B];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int npair = p.nb * (p.nb - 1) / 2;
+    int I, J;
+    const int task = blockIdx.x;
+    const bool diag = task >= npair;
+    if (diag) {
+        I = J = task - npair;
+    } else {
+        const float q = 2.0f * p.nb - 1.0f;
+        I = (int)((q - __builtin_sqrtf(q * q - 8.0f * (float)task)) * 0.5f);
+        if (I < 0) I = 0;
+        if (I > p.nb - 2) I = p.nb - 2;
+        while (I < p.nb - 2 && sym_row_offset(I + 1, p.nb) <= task) ++I;
+        while (I > 0 && sym_row_offset(I, p.nb) > task) --I;
+        J = I + 1 + (task - sym_row_offset(I, p.nb));
+    }
+
+    M t;
+    t.set_eps2(p.eps2);
+    const int ibase = I * B + w * (64 * BPL) + lane;
+#pragma unroll
+    for (int k = 0; k < BPL; ++k) {
+        const int i = ibase + k * 64;
+        t.set(k, i < p.n ? p.x[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    }
+    const int jbase = J * B + lane;
+    const int rot = ((lane + 16) & 63) << 2;
+
+    auto fetch = [&](int c) {
+        const int j = jbase + c * 64;
+        return j < p.n ? p.x[j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    };
+
+    if (!diag) {
+#pragma unroll
+        for (int e = tid; e < B; e += 64 * W) sh[e] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        __syncthreads();
+    }
+    int c = w * BPL;  // chunk of this wave in round 0 (distinct per wave, NCH = W*BPL chunks)
+    float4 nxt = fetch(c);
+    for (int q = 0; q < NCH; ++q) {
+        float4 bj = nxt;
+        const int cn = (c + 1 == NCH) ? 0 : c + 1;
+        if (q + 1 < NCH) nxt = fetch(cn);
+        if (diag) {
+            float4 aj;
+            for (int ph = 0; ph < 4; ++ph) {
+                sym_row_pass<false>(t, bj, aj);
+                bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot); bj.w = next_row(bj.w, rot);
+            }
+        } else {
+            float4 aj = sh[c * 64 + lane];
+            for (int ph = 0; ph < 4; ++ph) {
+                sym_row_pass<true>(t, bj, aj);
+                bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot); bj.w = next_row(bj.w, rot);
+                aj.x = next_row(aj.x, rot); aj.y = next_row(aj.y, rot); aj.z = next_row(aj.z, rot);
+            }
+            sh[c * 64 + lane] = aj;
+            __syncthreads();
+        }
+        c = cn;
+    }
+
+    float4* const out_i = p.slabs + (size_t)J * p.stride;
+#pragma unroll
+    for (int k = 0; k < BPL; ++k) {
+        const int i = ibase + k * 64;
+        if (i < p.n) out_i[i] = t.acc(k);
+    }
+    if (!diag) {
+        float4* const out_j = p.slabs + (size_t)I * p.stride;
+        for (int e = tid; e < B; e += 64 * W) {
+            const int j = J * B + e;
+            if (j < p.n) {
+                float4 a = sh[e];
+                a.w = 0.0f;
+                out_j[j] = a;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // strict flavour — the reference's arithmetic, operation by operation
 // ---------------------------------------------------------------------------------------
 

@@ -1,0 +1,225 @@
+// tools/symbench.hip — developer bench for the symmetric (each unordered pair once) force kernel
+// against the shipped one-sided LDS kernel: same bodies, same process, interleaved timing, and a
+// check of the accelerations of the two against each other and against an fp64 CPU sum on sampled
+// targets.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I n-bodysimulation_amd/csrc tools/symbench.hip -o build/symbench
+//   build/symbench [N] [reps]
+// Not part of the product; results feed DESIGN.md and profiles/.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "nbody_kernels.hip.h"
+
+#define CK(x)                                                                                     \
+    do {                                                                                          \
+        hipError_t e_ = (x);                                                                      \
+        if (e_ != hipSuccess) {                                                                   \
+            fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(2);                                                                              \
+        }                                                                                         \
+    } while (0)
+
+static uint64_t g_s = 12345;
+static double u01()
+{
+    g_s += 0x9E3779B97F4A7C15ull;
+    uint64_t z = g_s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// what each lane sees through row_ror:S (prints the lane mapping once, for the record)
+__global__ void dpp_probe(int* out)
+{
+    const int lane = threadIdx.x;
+    out[lane] = (int)nbk::ror<1>((float)lane);
+    out[64 + lane] = (int)nbk::ror<15>((float)lane);
+    out[128 + lane] = (int)nbk::next_row((float)lane, ((lane + 16) & 63) << 2);
+}
+
+static float median_ms(const std::function<void()>& f, int reps)
+{
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    f();
+    CK(hipDeviceSynchronize());
+    std::vector<float> ts;
+    for (int r = 0; r < reps; ++r) {
+        CK(hipEventRecord(e0));
+        f();
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        ts.push_back(ms);
+    }
+    std::sort(ts.begin(), ts.end());
+    CK(hipEventDestroy(e0));
+    CK(hipEventDestroy(e1));
+    return ts[ts.size() / 2];
+}
+
+struct SymVariant {
+    std::string name;
+    int B;
+    std::function<void(const nbk::SymParams&, int grid)> launch;
+};
+
+template <class M, int W>
+static SymVariant sym_variant(const char* name)
+{
+    return {name, 64 * W * M::BPL, [](const nbk::SymParams& p, int grid) { nbk::force_sym<M, W><<<grid, 64 * W>>>(p); }};
+}
+
+int main(int argc, char** argv)
+{
+    const int n = argc > 1 ? atoi(argv[1]) : 262144;
+    const int reps = argc > 2 ? atoi(argv[2]) : 5;
+    const bool plummer = argc > 3 ? atoi(argv[3]) != 0 : true;
+    const float eps2 = 0.002f;
+
+    {
+        int* d;
+        CK(hipMalloc(&d, 192 * sizeof(int)));
+        dpp_probe<<<1, 64>>>(d);
+        int h[192];
+        CK(hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
+        printf("row_ror:1  lane0..17 reads:");
+        for (int l = 0; l < 18; ++l) printf(" %d", h[l]);
+        printf("\nrow_ror:15 lane0..17 reads:");
+        for (int l = 0; l < 18; ++l) printf(" %d", h[64 + l]);
+        printf("\nnext_row   lane0,16,32,48 reads: %d %d %d %d\n", h[128], h[128 + 16], h[128 + 32], h[128 + 48]);
+        CK(hipFree(d));
+    }
+
+    std::vector<float4> hx(n);
+    for (int i = 0; i < n; ++i) {
+        if (plummer) {
+            // Plummer sphere a = 1, total mass 1
+            double r;
+            do { r = 1.0 / std::sqrt(std::pow(u01() * 0.999 + 1e-9, -2.0 / 3.0) - 1.0); } while (r > 50.0);
+            const double ct = 2.0 * u01() - 1.0, st = std::sqrt(1.0 - ct * ct), ph = 6.283185307179586 * u01();
+            hx[i] = make_float4((float)(r * st * std::cos(ph)), (float)(r * st * std::sin(ph)), (float)(r * ct), 1.0f / n);
+        } else {
+            hx[i] = make_float4((float)((2 * u01() - 1) * 1e5), (float)((2 * u01() - 1) * 1e5), (float)((2 * u01() - 1) * 1e5),
+                                (float)(1e5 + u01() * (1e9 - 1e5)));
+        }
+    }
+    float4 *dx, *da_ref, *da_sym, *slabs;
+    CK(hipMalloc(&dx, (size_t)n * 16));
+    CK(hipMalloc(&da_ref, (size_t)n * 16));
+    CK(hipMalloc(&da_sym, (size_t)n * 16));
+    CK(hipMemcpy(dx, hx.data(), (size_t)n * 16, hipMemcpyHostToDevice));
+    const int max_slabs = 1024;
+    CK(hipMalloc(&slabs, (size_t)max_slabs * n * 16));
+
+    auto reduce = [&](float4* out, int nslab) {
+        nbk::ReduceParams r{};
+        r.out = out; r.slabs = slabs; r.nslab = nslab; r.slab_stride = n; r.n = n; r.accumulate = 0;
+        nbk::reduce_slabs<<<(n + 255) / 256, 256>>>(r);
+    };
+
+    // shipped one-sided kernel
+    const int js = 16;
+    nbk::ForceParams fp{};
+    fp.x = dx; fp.out = slabs; fp.i0 = 0; fp.i1 = n; fp.j0 = 0; fp.j1 = n; fp.slab_stride = n; fp.accumulate = 0; fp.eps2 = eps2; fp.wrap = 0;
+    auto one_sided = [&] {
+        nbk::force_lds<nbk::MathPacked<4>, 2048, 8, 1><<<dim3((n + 1023) / 1024, js), 256>>>(fp);
+        reduce(da_ref, js);
+    };
+    one_sided();
+    CK(hipDeviceSynchronize());
+    std::vector<float4> a_ref(n), a_sym(n);
+    CK(hipMemcpy(a_ref.data(), da_ref, (size_t)n * 16, hipMemcpyDeviceToHost));
+
+    // fp64 truth on sampled targets
+    const int nsamp = 64;
+    std::vector<int> samp(nsamp);
+    std::vector<double> truth(3 * nsamp);
+    double amax = 0;
+    for (int s = 0; s < nsamp; ++s) {
+        const int i = (int)((long)s * (n - 1) / (nsamp - 1));
+        samp[s] = i;
+        double ax = 0, ay = 0, az = 0;
+        for (int j = 0; j < n; ++j) {
+            const double rx = (double)hx[j].x - hx[i].x, ry = (double)hx[j].y - hx[i].y, rz = (double)hx[j].z - hx[i].z;
+            const double d = rx * rx + ry * ry + rz * rz + (double)eps2;
+            const double f = hx[j].w / (d * std::sqrt(d));
+            ax += rx * f; ay += ry * f; az += rz * f;
+        }
+        truth[3 * s] = ax; truth[3 * s + 1] = ay; truth[3 * s + 2] = az;
+        amax = std::max(amax, std::sqrt(ax * ax + ay * ay + az * az));
+    }
+    auto err_vs_truth = [&](const std::vector<float4>& a) {
+        double e = 0;
+        for (int s = 0; s < nsamp; ++s) {
+            const float4 q = a[samp[s]];
+            e = std::max(e, std::fabs(q.x - truth[3 * s]));
+            e = std::max(e, std::fabs(q.y - truth[3 * s + 1]));
+            e = std::max(e, std::fabs(q.z - truth[3 * s + 2]));
+        }
+        return e / amax;
+    };
+    printf("N=%d %s  one-sided vs fp64 truth: %.3g of max|a|\n", n, plummer ? "plummer" : "cube", err_vs_truth(a_ref));
+
+    std::vector<SymVariant> vars;
+    vars.push_back(sym_variant<nbk::SymPacked<8>, 8>("sym packed bpl8 w8 (B=4096)"));
+    vars.push_back(sym_variant<nbk::SymPacked<8>, 4>("sym packed bpl8 w4 (B=2048)"));
+    vars.push_back(sym_variant<nbk::SymPacked<4>, 8>("sym packed bpl4 w8 (B=2048)"));
+    vars.push_back(sym_variant<nbk::SymPacked<4>, 4>("sym packed bpl4 w4 (B=1024)"));
+    vars.push_back(sym_variant<nbk::SymScalar<8>, 8>("sym scalar bpl8 w8 (B=4096)"));
+    vars.push_back(sym_variant<nbk::SymScalar<8>, 4>("sym scalar bpl8 w4 (B=2048)"));
+    vars.push_back(sym_variant<nbk::SymScalar<4>, 8>("sym scalar bpl4 w8 (B=2048)"));
+    vars.push_back(sym_variant<nbk::SymScalar<4>, 4>("sym scalar bpl4 w4 (B=1024)"));
+
+    const double pairs = (double)n * n;
+    const float t_ref = median_ms(one_sided, reps);
+    printf("%-34s %8.3f ms  %.3e pairs/s  %.1f%% of 157.3 TF\n", "one-sided lds packed bpl4 t2048", t_ref, pairs / t_ref * 1e3,
+           20 * pairs / t_ref * 1e3 / 157.3e12 * 100);
+    for (auto& v : vars) {
+        const int nb = (n + v.B - 1) / v.B;
+        if (nb > max_slabs || nb < 2) continue;
+        nbk::SymParams sp{};
+        sp.x = dx; sp.slabs = slabs; sp.n = n; sp.nb = nb; sp.stride = n; sp.eps2 = eps2;
+        const int grid = nb * (nb - 1) / 2 + nb;
+        auto run = [&] {
+            v.launch(sp, grid);
+            reduce(da_sym, nb);
+        };
+        CK(hipMemset(slabs, 0xff, (size_t)nb * n * 16));  // NaN fill: an unwritten slab element shows up
+        run();
+        CK(hipGetLastError());
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(a_sym.data(), da_sym, (size_t)n * 16, hipMemcpyDeviceToHost));
+        double dmax = 0, scale = 0;
+        for (int i = 0; i < n; ++i) {
+            scale = std::max(scale, (double)std::fabs(a_ref[i].x));
+            scale = std::max(scale, (double)std::fabs(a_ref[i].y));
+            scale = std::max(scale, (double)std::fabs(a_ref[i].z));
+        }
+        long bad = 0;
+        for (int i = 0; i < n; ++i) {
+            const double e = std::max({std::fabs((double)a_ref[i].x - a_sym[i].x), std::fabs((double)a_ref[i].y - a_sym[i].y),
+                                       std::fabs((double)a_ref[i].z - a_sym[i].z)});
+            if (!(e <= 1e30)) ++bad;
+            else dmax = std::max(dmax, e);
+        }
+        const float ms = median_ms(run, reps);
+        const float t2 = median_ms(one_sided, reps);
+        printf("%-34s %8.3f ms  %.3e pairs/s  %.1f%% of 157.3 TF | vs one-sided max diff %.3g of max|a|, nonfinite %ld, vs truth %.3g | one-sided again %.3f ms\n",
+               v.name.c_str(), ms, pairs / ms * 1e3, 20 * pairs / ms * 1e3 / 157.3e12 * 100, dmax / scale, bad, err_vs_truth(a_sym), t2);
+        fflush(stdout);
+    }
+    return 0;
+}
