@@ -8,22 +8,33 @@
 A "step" is one pass of the hot path over all bodies: the O(N^2) force accumulation followed by
 the half-kick/drift integrate (TestProject/kernel.cu:80-130 in the reference).
 
-Workload (BASELINE.json): N = 262144 bodies, fp32, 1 GPU (configs[2], the size the metric is quoted
-on). With G > 1 ranks the bodies are block-partitioned and positions all-gathered once per step
-(RCCL); the run is WEAK-scaled: N(G) = 262144 * sqrt(G) rounded to a multiple of 8192*G (376832,
-524288, 720896 bodies at G = 2, 4, 8), so every GPU evaluates 6.9e10 (+-5 %) pairs per step. `--bodies` overrides (e.g. --bodies 1048576 for configs[3]).
+Workload (BASELINE.json):
+  --gpus 1   N = 262144 bodies, fp32 (configs[2], the size the metric is quoted on).
+  --gpus G>1 N = 1048576 bodies (configs[3]) block-partitioned over the G ranks, positions all-gathered
+             once per step (RCCL); STRONG scaling: the same system at every G. `--scaling weak` instead
+             runs N(G) = 262144*sqrt(G) rounded to 8192*G bodies (equal pairs per GPU).
+  --bodies overrides N; --dtype f64 is configs[4] (single GPU).
 
-Rank 0 prints ONE JSON line. `value` = N^2 * steps / wall time of the timed region (max over
-ranks), inputs resident in HBM before the region starts. `roofline` is the force kernel's
-algorithmic FLOP rate (20 FLOP/pair) over its own HIP-event time on its launch
-stream, against the 157.3 TFLOP/s fp32 vector peak; `cpu_baseline` times the reference's own CPU
-path (oracle/_ref, kind "reference") or the checker's restatement (kind "port") on a bounded
-sample on the host cores — a reported baseline, not the product.
+Timing: W warm-up steps, then R repeats (R >= 3, enough for >= 3 s in all; --repeats overrides) of
+EXACTLY K steps each, every repeat bracketed by a barrier + device synchronise on both sides and
+reduced with MAX over ranks. `ms_per_step` and `value` come from the MEDIAN repeat; min/max are
+reported beside it. `value` = N^2 * K / (median repeat time): interactions applied per second, inputs
+resident in HBM before the first repeat starts.
+
+`roofline` is the force kernel's algorithmic FLOP rate — 20 FLOP per interaction times
+the N^2 interactions one launch applies — over its own HIP-event time on its launch stream, against the
+157.3 TFLOP/s fp32 vector peak. The symmetric kernel EVALUATES each unordered pair once (about N^2/2
+evaluations for the same N^2 interactions); `evaluated_pairs_per_launch` and `frac_evaluated` state the
+figure on that count as well. `cpu_baseline` times the reference's own CPU path (oracle/_ref, kind
+"reference") or the checker's restatement (kind "port") on a bounded sample on the host cores — a
+reported baseline, not the product.
 """
 import argparse
+import fcntl
 import json
 import math
 import os
+import statistics
 import sys
 import time
 
@@ -31,18 +42,38 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-FLOP_PER_PAIR = 20.0            # the agreed algorithmic count
+FLOP_PER_PAIR = 20.0             # the agreed algorithmic count
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
-BASE_N = 262144
+FP64_VECTOR_PEAK_TFLOPS = 78.6
+N_SINGLE = 262144                # BASELINE.json configs[2]
+N_MULTI = 1048576                # BASELINE.json configs[3]
 
 
 def weak_n(gpus: int) -> int:
     if gpus == 1:
-        return BASE_N
-    # every rank's block a multiple of 8192 bodies (8 target workgroups): shapes with an odd number of
-    # target workgroups run 2-4 % slower (tools/shape_probe.py), which would be a shape artefact, not scaling
+        return N_SINGLE
+    # every rank's block a multiple of 8192 bodies
     q = 8192 * gpus
-    return int(round(BASE_N * math.sqrt(gpus) / q)) * q
+    return int(round(N_SINGLE * math.sqrt(gpus) / q)) * q
+
+
+def ensure_built() -> None:
+    """Build the in-tree binaries if a snapshot lacks them — under an exclusive file lock, so that with
+    several ranks starting at once exactly one compiles and the others wait for the finished library
+    (never a half-written one). Runs before anything touches the GPU or the process group."""
+    import nbody_amd
+    need = [nbody_amd._lib.LIB_PATH]
+    if all(os.path.exists(p) for p in need):
+        return
+    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+    with open(os.path.join(ROOT, "build", ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not all(os.path.exists(p) for p in need):
+                import __graft_entry__
+                __graft_entry__.build()
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 def cpu_baseline(seconds_budget: float = 12.0):
@@ -69,7 +100,8 @@ def cpu_baseline(seconds_budget: float = 12.0):
     dt = time.perf_counter() - t0
     out.update({"value": n * (n - 1) * done / dt, "unit": "pairs/s", "cores": 1, "kind": kind,
                 "sample": f"{done} serial in-place steps of validation.cpp:28-52 at N={n} (reference init, DT=0.1, EPS2=0.002), {dt:.1f} s"})
-    # the best honest CPU line: our Jacobi restatement, SIMD over targets, OpenMP over all cores
+    # context only: our Jacobi restatement, SIMD over targets, OpenMP over all cores (varies a lot
+    # between boxes of the pool — the serial reference figure above is the stated baseline)
     thr = O.max_threads()
     O.set_threads(thr)
     O.accel_range(x0, 0, n)          # spin up the thread pool
@@ -86,18 +118,46 @@ def cpu_baseline(seconds_budget: float = 12.0):
     return out
 
 
+def cpu_baseline_f64(seconds_budget: float = 10.0):
+    """The checker's all-double Jacobi step (the fp64 variant has no reference counterpart: kind "port")."""
+    import numpy as np
+    from oracle import oracle as O
+    import nbody_amd
+    n = 8192
+    x0 = nbody_amd.engine.seeded_bodies(n, 1, 12345).astype(np.float64)
+    O.set_threads(1)
+    x, v, a = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
+    O.step_jacobi_f64(x, a, v, 0.01, 0.002, steps=1)
+    t0 = time.perf_counter()
+    done = 0
+    while done < 64:
+        O.step_jacobi_f64(x, a, v, 0.01, 0.002, steps=1)
+        done += 1
+        if time.perf_counter() - t0 > seconds_budget:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": float(n) * n * done / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
+            "sample": f"{done} all-double Jacobi steps of the checker at N={n} (Plummer), one thread, {dt:.1f} s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--bodies", dest="n", type=int, default=0, help="number of bodies (default: weak-scaled from 262144)")
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=0, help="timed repeats of --steps steps (0 = auto: >= 3 and >= 3 s in all)")
+    ap.add_argument("--bodies", dest="n", type=int, default=0, help="number of bodies (default: 262144 on 1 GPU, 1048576 on several)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="--gpus > 1 without --bodies: strong = N 1048576 "
+                    "at every G (default, BASELINE configs[3]); weak = 262144*sqrt(G) bodies")
     ap.add_argument("--dt", type=float, default=0.01)
     ap.add_argument("--eps2", type=float, default=0.002)
     ap.add_argument("--init", type=int, default=1, help="0 reference cube, 1 Plummer")
+    ap.add_argument("--kernel", default="fast", choices=["fast", "onesided", "symmetric"])
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--bpl", type=int, default=0)
     ap.add_argument("--jsplit", type=int, default=0)
+    ap.add_argument("--sym-waves", type=int, default=0)
+    ap.add_argument("--sym-bpl", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="f64 = the build's own double-precision variant "
                     "(BASELINE configs[4]; single GPU only)")
@@ -105,12 +165,12 @@ def main():
                     "(rehearsal of the multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
+    ensure_built()   # before the process group and before any GPU call; ranks serialise on a file lock
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     import nbody_amd
-    if not os.path.exists(nbody_amd._lib.LIB_PATH) and int(os.environ.get("RANK", "0")) == 0:
-        import __graft_entry__            # un-built snapshot: compile the HIP library in-tree first
-        __graft_entry__.build()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -132,16 +192,23 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    n = args.n or weak_n(world)
+    if args.n:
+        n, scaling = args.n, ("strong" if world > 1 else "weak")
+    elif world == 1:
+        n, scaling = N_SINGLE, "weak"
+    elif args.scaling == "weak":
+        n, scaling = weak_n(world), "weak"
+    else:
+        n, scaling = N_MULTI, "strong"
     x0 = nbody_amd.engine.seeded_bodies(n, args.init, 12345)
-    kopts = dict(tile=args.tile, bodies_per_lane=args.bpl, jsplit=args.jsplit)
+    kernel = {"fast": nbody_amd.KERNEL_FAST, "onesided": nbody_amd.KERNEL_ONESIDED, "symmetric": nbody_amd.KERNEL_SYMMETRIC}[args.kernel]
+    kopts = dict(kernel=kernel, tile=args.tile, bodies_per_lane=args.bpl, jsplit=args.jsplit)
 
     f64 = args.dtype == "f64"
     if f64 and world > 1:
         raise SystemExit("--dtype f64 is a single-GPU variant")
+    backend = None
     if f64:
-        import numpy as np
-
         class _F64Sim:   # same alloc/init/H2D sequence as engine.Simulation, double state
             def __init__(self):
                 self.ctx = nbody_amd.engine.Context(device=dev.index, jsplit=args.jsplit)
@@ -149,6 +216,7 @@ def main():
                 self.v = torch.zeros_like(self.x)
                 self.a = torch.zeros_like(self.x)
                 self.shard, self.n_pad = n, n
+                torch.cuda.synchronize(dev)
 
             def run(self, k, sync=False):
                 self.ctx.step_f64(self.x, self.a, self.v, args.dt, args.eps2, k)
@@ -157,20 +225,26 @@ def main():
         ctx = sim.ctx
         run = lambda k: sim.run(k)
         sync = ctx.sync
-        info = {"jsplit": args.jsplit or "auto", "kernel": "nbk::force_f64<2,512>"}
+        info = {"symmetric": False, "slabs": args.jsplit or "auto", "kernel": "nbk::force_f64<2,512>", "evaluated_pairs": float(n) * n}
     elif world == 1:
         sim = nbody_amd.engine.Simulation(x0, dt=args.dt, eps2=args.eps2, device=dev.index, **kopts)
         ctx = sim.ctx
+        if args.sym_waves or args.sym_bpl:
+            ctx.set_symmetric_shape(args.sym_waves, args.sym_bpl)
+            ctx.reserve(n)
         run = lambda k: sim.run(k, sync=False)
         sync = ctx.sync
-        info = ctx.launch_info(n, n)
+        info = ctx.step_info(n)
     else:
         backend = nbody_amd.sharded.HipBackend(dev, args.dt, args.eps2, **kopts)
         sim = nbody_amd.sharded.ShardedSimulation(x0, dt=args.dt, eps2=args.eps2, backend=backend)
         ctx = sim.backend.ctx
         run = sim.step
         sync = sim.sync
-        info = ctx.launch_info(sim.shard, sim.shard)   # the local pass; the remote passes differ in source count
+        info = ctx.step_info(sim.shard)   # the own-block pass; the remote pass is one one-sided launch over the other blocks
+        info["evaluated_pairs"] += float(sim.shard) * (sim.n_pad - sim.shard)
+
+    red_dev = dev if args.backend == "nccl" else "cpu"
 
     def barrier():
         sync()
@@ -178,40 +252,69 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def max_over_ranks(v: float) -> float:
+        if world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     run(args.warmup)
     barrier()
     if world > 1:
         backend.comm_timing = True
     ctx.timing(True)
-    t0 = time.perf_counter()
-    run(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    force_ms, launches = ctx.timing_read()
+    repeats, kernel_ms, kernel_launches = [], [], 0
+    target = args.repeats if args.repeats > 0 else 3
+    while len(repeats) < target:
+        barrier()
+        t0 = time.perf_counter()
+        run(args.steps)              # EXACTLY K steps per timed region
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        ms, launches = ctx.timing_read()
+        repeats.append(elapsed)
+        kernel_ms.append(ms)
+        kernel_launches += launches
+        if args.repeats <= 0 and len(repeats) == 1:
+            target = min(max(3, int(math.ceil(3.0 / max(elapsed, 1e-6)))), 25)   # same on every rank: from the reduced time
     ctx.timing(False)
     comm = backend.comm_report() if world > 1 else None
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    pairs_total = float(n) * n * args.steps
-    value = pairs_total / elapsed
+    elapsed = statistics.median(repeats)
+    pairs_step = float(n) * n
+    value = pairs_step * args.steps / elapsed
     # roofline of the dominant kernel (force accumulation), from its own event time on this rank
-    rank_pairs = float(sim.shard) * sim.n_pad * args.steps if world > 1 else pairs_total
-    kernel_s = force_ms * 1e-3
-    if f64:   # the fp64 launches are not event-bracketed: the step is >99.9 % force kernel, use the wall time
-        kernel_s, launches, force_ms = elapsed, args.steps, elapsed * 1e3
-    achieved = FLOP_PER_PAIR * rank_pairs / kernel_s / 1e12 if kernel_s > 0 else 0.0
-    peak = 78.6 if f64 else FP32_VECTOR_PEAK_TFLOPS
-    traffic = None
+    rank_pairs = float(sim.shard) * sim.n_pad if world > 1 else pairs_step            # interactions this rank applies per step
+    launches_per_step = max(kernel_launches // (len(repeats) * args.steps), 1)
+    kernel_s_step = sum(kernel_ms) * 1e-3 / (len(repeats) * args.steps)                 # force-kernel time per step
+    achieved = FLOP_PER_PAIR * rank_pairs / kernel_s_step / 1e12 if kernel_s_step > 0 else 0.0
+    evaluated = float(info["evaluated_pairs"])
+    achieved_eval = FLOP_PER_PAIR * evaluated / kernel_s_step / 1e12 if kernel_s_step > 0 else 0.0
+    peak = FP64_VECTOR_PEAK_TFLOPS if f64 else FP32_VECTOR_PEAK_TFLOPS
+    symmetric = bool(info.get("symmetric"))
+    traffic = traffic_note = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if world == 1 and n == BASE_N and not f64 and os.path.exists(tpath):   # the PMC passes were taken on this workload only
-        try:
-            traffic = json.load(open(tpath)).get("force_kernel_hbm_bytes_per_launch")
+    if world == 1 and not f64 and os.path.exists(tpath):
+        try:   # PMC passes are taken offline (tools/pmc.sh); valid only for the launch shape they were taken at
+            t = json.load(open(tpath))
+            if t.get("n_bodies") == n and t.get("symmetric") == symmetric and t.get("slabs") == info.get("slabs"):
+                traffic = t.get("force_kernel_hbm_bytes_per_launch")
+                traffic_note = t.get("note")
         except Exception:
             traffic = None
+
+    fp_diff = None
+    if f64:
+        # configs[4]'s tolerance check: the fp32 engine from the same start, same number of steps
+        total_steps = args.warmup + args.steps * len(repeats)
+        s32 = nbody_amd.engine.Simulation(x0, dt=args.dt, eps2=args.eps2, device=dev.index)
+        s32.run(total_steps)
+        x32 = s32.state()[0].astype(np.float64)
+        x64 = sim.x.cpu().numpy()
+        scale = float(np.abs(x64[:, :3]).max()) if args.init == 0 else 1.0     # Plummer: scale radius a = 1
+        fp_diff = {"steps": total_steps, "max_abs_dx": float(np.abs(x32 - x64)[:, :3].max()),
+                   "max_rel_dx": float(np.abs(x32 - x64)[:, :3].max() / scale), "scale": scale}
 
     line = {
         "metric": "body_pair_interactions_per_s",
@@ -222,19 +325,23 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic",
+        "repeats": len(repeats),
+        "ms_per_step_min": min(repeats) / args.steps * 1e3,
+        "ms_per_step_max": max(repeats) / args.steps * 1e3,
         "config": {
             "workload": f"all-pairs gravity step, N={n} bodies, {'fp64' if f64 else 'fp32'}, {'Plummer' if args.init == 1 else 'reference-cube'} init seed 12345, "
-                        f"dt={args.dt}, eps2={args.eps2}",
+                        f"dt={args.dt}, eps2={args.eps2}" + (f", {world} GPUs, {scaling} scaling" if world > 1 else ""),
             "n_bodies": n,
-            "pairs_per_step": float(n) * n,
+            "pairs_per_step": pairs_step,
             "partition": "single GPU" if world == 1 else f"{world} contiguous blocks of {sim.shard} bodies, {args.backend} all-gather of positions per step",
             "kernel": nbody_amd.load().nbody_version().decode(),
             "launch": info,
             "gflops_at_20_flop_per_pair": value * FLOP_PER_PAIR / 1e9,
+            **({"fp32_vs_fp64": fp_diff} if fp_diff else {}),
             **({"comm_rank0": comm} if comm else {}),
         },
         "roofline": {
@@ -244,18 +351,26 @@ def main():
             "unit": "TFLOP/s",
             "frac": achieved / peak,
             "traffic": traffic,
-            "kernel": "nbk::force_f64" if f64 else "nbk::force_lds (fp32 packed)",
-            "kernel_ms_avg": force_ms / max(launches, 1),
-            "kernel_launches": launches,
+            **({"traffic_note": traffic_note} if traffic_note else {}),
+            "kernel": "nbk::force_f64" if f64 else ("nbk::force_sym (fp32 packed, each unordered pair once)" if symmetric else "nbk::force_lds (fp32 packed, one-sided)"),
+            "kernel_ms_per_step": kernel_s_step * 1e3,
+            "kernel_launches_per_step": launches_per_step,
+            "kernel_launches": kernel_launches,
             "flop_per_pair": FLOP_PER_PAIR,
+            "interactions_per_step": rank_pairs,
+            "evaluated_pairs_per_step": evaluated,
+            "achieved_evaluated": achieved_eval,
+            "frac_evaluated": achieved_eval / peak,
             "note": ("fp64 vector-ALU bound; peak = 78.6 TFLOP/s fp64 vector" if f64 else
-                     "fp32 vector-ALU bound (no MFMA, HBM traffic is O(N) per step); peak = 157.3 TFLOP/s fp32 vector = fp32 MFMA peak"),
+                     "fp32 vector-ALU bound (no MFMA, HBM traffic is O(N) per step); peak = 157.3 TFLOP/s fp32 vector = fp32 MFMA peak. "
+                     "achieved/frac: 20 FLOP x interactions applied (N^2, the metric's convention); achieved_evaluated/frac_evaluated: "
+                     "20 FLOP x pair evaluations actually executed (the symmetric kernel evaluates each unordered pair once and applies it to both bodies)"),
         },
     }
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline and not f64:
+        if world == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline()
+                line["cpu_baseline"] = cpu_baseline_f64() if f64 else cpu_baseline()
             except Exception as e:  # the baseline must never take the GPU number down with it
                 line["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(line), flush=True)

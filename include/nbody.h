@@ -60,10 +60,17 @@ enum {
 
 /* Arithmetic flavour of the force kernel. */
 enum {
-    NBODY_KERNEL_FAST = 0,  /* packed fp32, v_rsq_f32, fma; tolerance-level parity            */
-    NBODY_KERNEL_STRICT = 1 /* the reference's operation order with IEEE sqrt/div, no fma    */
-                            /* contraction, j==i skipped: bit-identical to validation.cpp's  */
-                            /* arithmetic taken in Jacobi order                              */
+    NBODY_KERNEL_FAST = 0,      /* packed fp32, v_rsq_f32, fma; tolerance-level parity. A whole step (or a  */
+                                /* square block of nbody_accel_range) of >= 16384 bodies runs the SYMMETRIC */
+                                /* kernel, anything else the ONESIDED one                                   */
+    NBODY_KERNEL_STRICT = 1,    /* the reference's operation order with IEEE sqrt/div, no fma contraction,  */
+                                /* j==i skipped: bit-identical to validation.cpp's arithmetic taken in      */
+                                /* Jacobi order                                                             */
+    NBODY_KERNEL_ONESIDED = 2,  /* FAST arithmetic, always the one-sided LDS-tiled kernel: every target     */
+                                /* evaluates all N sources (N*N pair evaluations, as kernel.cu:55-65 does)  */
+    NBODY_KERNEL_SYMMETRIC = 3  /* FAST arithmetic, every unordered pair evaluated once and applied to both */
+                                /* bodies (N*N/2 evaluations for the same N*N interactions); square problems */
+                                /* of at least two blocks, otherwise falls back to ONESIDED                 */
 };
 
 /* constants.h:25-26 */
@@ -109,6 +116,11 @@ int nbody_ctx_set_params(nbody_ctx* ctx, float dt, float eps2);
  * THREADS_PER_BLOCK*TILE_WIDTH_FACTOR, constants.h:11-12, is 32); bodies_per_lane: register
  * blocking (0 = default 4); jsplit: source-range slabs per launch (0 = auto from N). */
 int nbody_ctx_set_kernel(nbody_ctx* ctx, int kernel, int tile, int bodies_per_lane, int jsplit);
+
+/* Shape of the symmetric kernel: wave64s per workgroup and stationary bodies per lane; a block is
+ * 64*waves*bodies_per_lane bodies. Built: (4,8) (2,8) (2,4) (1,4) (1,2); 0 = auto (the largest block that
+ * still gives 64 blocks). */
+int nbody_ctx_set_symmetric_shape(nbody_ctx* ctx, int waves, int bodies_per_lane);
 
 /* Launch on this HIP stream (a hipStream_t passed as void*; NULL = the context's own stream). */
 int nbody_ctx_set_stream(nbody_ctx* ctx, void* hip_stream);
@@ -196,6 +208,13 @@ const char* nbody_version(void);
  * blocks, LDS bytes per block. Any out pointer may be NULL. */
 int nbody_ctx_launch_info(nbody_ctx* ctx, int n_targets, int n_sources, int* jsplit, int* blocks,
                           int* lds_bytes);
+
+/* What nbody_step() does for n bodies: symmetric = 1 when the symmetric kernel runs; block_bodies = bodies
+ * per block (symmetric) or per workgroup (one-sided); slabs = partial-sum slabs the integrate adds;
+ * workgroups = grid size; evaluated_pairs = pair evaluations per step (n*n one-sided; about n*n/2 plus
+ * the diagonal blocks symmetric — the interactions applied are n*n either way). Any out pointer may be NULL. */
+int nbody_ctx_step_info(nbody_ctx* ctx, int n, int* symmetric, int* block_bodies, int* slabs, int* workgroups,
+                        double* evaluated_pairs);
 
 /* The same resolution without a context or a device (pure host logic, for tests and tooling):
  * given the user's kernel/tile/bodies_per_lane/jsplit choices (0 = auto) and a CU count, what the

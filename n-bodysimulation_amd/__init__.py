@@ -3,10 +3,10 @@ LienoPC/N-BodySimulation). See DESIGN.md and include/nbody.h.
 
 The directory name carries a hyphen, so import it through the repo-root shim:
 ``import nbody_amd`` (or ``importlib`` with this directory as the package path)."""
-from ._lib import (DEFAULT_DT, DEFAULT_EPS2, KERNEL_FAST, KERNEL_STRICT, NBodyError, exported_symbols,  # noqa: F401
+from ._lib import (DEFAULT_DT, DEFAULT_EPS2, KERNEL_FAST, KERNEL_ONESIDED, KERNEL_STRICT, KERNEL_SYMMETRIC, NBodyError, exported_symbols,  # noqa: F401
                    load)
 
-__all__ = ["DEFAULT_DT", "DEFAULT_EPS2", "KERNEL_FAST", "KERNEL_STRICT", "NBodyError", "exported_symbols", "load"]
+__all__ = ["DEFAULT_DT", "DEFAULT_EPS2", "KERNEL_FAST", "KERNEL_ONESIDED", "KERNEL_STRICT", "KERNEL_SYMMETRIC", "NBodyError", "exported_symbols", "load"]
 
 
 def __getattr__(name):

@@ -18,8 +18,10 @@ ERR_HIP = 2
 ERR_CONFIG = 3
 ERR_NOMEM = 4
 
-KERNEL_FAST = 0
+KERNEL_FAST = 0       # symmetric kernel for whole steps / square blocks of >= 16384 bodies, else one-sided
 KERNEL_STRICT = 1
+KERNEL_ONESIDED = 2   # fast arithmetic, every target evaluates all N sources
+KERNEL_SYMMETRIC = 3  # fast arithmetic, every unordered pair once (Newton's third law)
 
 DEFAULT_EPS2 = 0.002  # constants.h:25
 DEFAULT_DT = 0.1      # constants.h:26
@@ -44,6 +46,7 @@ _SIGNATURES = {
     "nbody_ctx_destroy": (C.c_int, [_p]),
     "nbody_ctx_set_params": (C.c_int, [_p, C.c_float, C.c_float]),
     "nbody_ctx_set_kernel": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "nbody_ctx_set_symmetric_shape": (C.c_int, [_p, C.c_int, C.c_int]),
     "nbody_ctx_set_stream": (C.c_int, [_p, _p]),
     "nbody_ctx_reserve": (C.c_int, [_p, C.c_int]),
     "nbody_ctx_set_graph": (C.c_int, [_p, C.c_int]),
@@ -71,6 +74,7 @@ _SIGNATURES = {
     "nbody_last_error": (C.c_char_p, []),
     "nbody_version": (C.c_char_p, []),
     "nbody_plan": (C.c_int, [C.c_int] * 7 + [C.POINTER(C.c_int)] * 4),
+    "nbody_ctx_step_info": (C.c_int, [_p, C.c_int] + [C.POINTER(C.c_int)] * 4 + [C.POINTER(C.c_double)]),
     "nbody_ctx_launch_info": (C.c_int, [_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                          C.POINTER(C.c_int)]),
 }

@@ -42,6 +42,33 @@ int fail(int code, const char* fmt, ...)
                         __FILE__, __LINE__);                                                \
     } while (0)
 
+// Makes `device` current for the scope of an entry point and puts the caller's device back afterwards
+// (the reference never calls cudaSetDevice: a caller's current device must survive our calls).
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device)
+    {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) {
+            err = hipSetDevice(device);
+            changed = (err == hipSuccess);
+        }
+    }
+    ~DeviceGuard()
+    {
+        if (changed) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+#define ON_DEVICE(c)                                                                                     \
+    DeviceGuard device_guard_((c)->device);                                                              \
+    if (device_guard_.err != hipSuccess)                                                                 \
+        return fail(NBODY_ERR_HIP, "cannot select device %d: %s", (c)->device, hipGetErrorString(device_guard_.err))
+
 constexpr int kMaxSplit = 64;
 constexpr int kGraphMaxN = 16384;  // below this a step is a few tens of microseconds: launch-bound
 constexpr int kGraphChunk = 32;    // steps per graph launch
@@ -58,6 +85,8 @@ struct nbody_ctx {
     int tile = 0;    // 0 = auto
     int bpl = 0;     // 0 = auto
     int jsplit = 0;  // 0 = auto
+    int sym_waves = 0;  // symmetric kernel: waves per workgroup (0 = auto)
+    int sym_bpl = 0;    // symmetric kernel: stationary bodies per lane (0 = auto)
     int num_cu = 256;
     void* slabs = nullptr;     // workspace: jsplit slabs of n_targets float4 (or double4)
     size_t slab_bytes = 0;
@@ -156,6 +185,48 @@ Shape resolve_shape(const nbody_ctx* c, int n_targets, int n_sources)
     return s;
 }
 
+// The symmetric kernel's decomposition: blocks of B = 64*waves*bpl bodies, one workgroup per block
+// pair (I <= J), one slab per block.
+struct SymShape {
+    int waves, bpl, block, nb, grid;
+};
+
+constexpr int kSymMinAuto = 16384;  // FAST switches to the symmetric kernel from this many bodies
+constexpr int kSymMaxSlabs = 1024;
+
+// (waves, bodies per lane) instantiated below, largest block first
+const int kSymCand[][2] = {{4, 8}, {2, 8}, {2, 4}, {1, 4}, {1, 2}};
+constexpr int kSymCands = 5;
+
+bool sym_resolve(const nbody_ctx* c, int n, SymShape* out)
+{
+    int pick = -1;
+    for (int k = 0; k < kSymCands; ++k) {
+        if ((c->sym_waves && kSymCand[k][0] != c->sym_waves) || (c->sym_bpl && kSymCand[k][1] != c->sym_bpl)) continue;
+        pick = k;
+        // enough block pairs to keep every CU busy through the tail: nb >= 64 gives 2080 tasks
+        if ((long)n >= 64L * 64 * kSymCand[k][0] * kSymCand[k][1]) break;
+    }
+    if (pick < 0) return false;
+    SymShape y{};
+    y.waves = kSymCand[pick][0];
+    y.bpl = kSymCand[pick][1];
+    y.block = 64 * y.waves * y.bpl;
+    y.nb = (n + y.block - 1) / y.block;
+    y.grid = y.nb * (y.nb - 1) / 2 + y.nb;
+    if (y.nb < 2 || y.nb > kSymMaxSlabs) return false;
+    *out = y;
+    return true;
+}
+
+// Does a square problem of n bodies (targets == sources) go to the symmetric kernel?
+bool sym_wanted(const nbody_ctx* c, int n, SymShape* out)
+{
+    if (c->kernel == NBODY_KERNEL_SYMMETRIC) return sym_resolve(c, n, out);
+    if (c->kernel == NBODY_KERNEL_FAST && n >= kSymMinAuto) return sym_resolve(c, n, out);
+    return false;
+}
+
 int ensure_slabs(nbody_ctx* c, size_t bytes)
 {
     if (bytes <= c->slab_bytes) return NBODY_OK;
@@ -226,14 +297,47 @@ int launch_force_untimed(nbody_ctx* c, const Shape& s, const nbk::ForceParams& p
     return NBODY_OK;
 }
 
+int launch_sym_untimed(nbody_ctx* c, const SymShape& y, const nbk::SymParams& p)
+{
+    using nbk::SymPacked;
+    const int key = y.waves * 100 + y.bpl;
+    switch (key) {
+        case 408: nbk::force_sym<SymPacked<8>, 4><<<y.grid, 256, 0, c->stream>>>(p); break;
+        case 208: nbk::force_sym<SymPacked<8>, 2><<<y.grid, 128, 0, c->stream>>>(p); break;
+        case 204: nbk::force_sym<SymPacked<4>, 2><<<y.grid, 128, 0, c->stream>>>(p); break;
+        case 104: nbk::force_sym<SymPacked<4>, 1><<<y.grid, 64, 0, c->stream>>>(p); break;
+        case 102: nbk::force_sym<SymPacked<2>, 1><<<y.grid, 64, 0, c->stream>>>(p); break;
+        default: return fail(NBODY_ERR_CONFIG, "no symmetric kernel for waves=%d bodies_per_lane=%d", y.waves, y.bpl);
+    }
+    HIP_TRY(hipGetLastError());
+    return NBODY_OK;
+}
+
+int launch_sym(nbody_ctx* c, const SymShape& y, const nbk::SymParams& p)
+{
+    if (int rc = time_mark(c)) return rc;
+    if (int rc = launch_sym_untimed(c, y, p)) return rc;
+    return time_mark(c);
+}
+
 int check_ctx(const nbody_ctx* c)
 {
     if (!c) return fail(NBODY_ERR_INVALID, "null context");
     return NBODY_OK;
 }
 
-std::mutex g_default_mu;
-nbody_ctx* g_default = nullptr;
+// One default context per device, created on first use and released at process exit. A recursive
+// mutex serialises the entry points that work on them (nbody_simulate, nbody_simulate_host_legacy).
+constexpr int kMaxDevices = 64;
+std::recursive_mutex g_default_mu;
+struct DefaultContexts {
+    nbody_ctx* ctx[kMaxDevices] = {};
+    ~DefaultContexts()
+    {
+        // at static destruction the HIP runtime may already be gone: release host state only
+        for (nbody_ctx*& c : ctx) { delete c; c = nullptr; }
+    }
+} g_default;
 
 }  // namespace
 
@@ -243,7 +347,7 @@ const char* nbody_last_error(void) { return g_err; }
 
 const char* nbody_version(void)
 {
-    return "nbody_hip 0.1 gfx950 fast=lds-packed(bpl4,tile2048,u8) strict=ieee-seq f64=lds";
+    return "nbody_hip 0.2 gfx950 fast=symmetric-dpp(w4,bpl8)|onesided-lds-packed(bpl4,tile2048,u8) strict=ieee-seq f64=lds";
 }
 
 int nbody_device_count(int* count)
@@ -268,7 +372,8 @@ int nbody_ctx_create(nbody_ctx** out, int device)
     if (ndev <= 0) return fail(NBODY_ERR_HIP, "no HIP device visible");
     if (device < 0) HIP_TRY(hipGetDevice(&device));
     if (device >= ndev) return fail(NBODY_ERR_INVALID, "device %d out of range (%d devices)", device, ndev);
-    HIP_TRY(hipSetDevice(device));
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return fail(NBODY_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(guard.err));
     nbody_ctx* c = new (std::nothrow) nbody_ctx();
     if (!c) return fail(NBODY_ERR_NOMEM, "out of host memory");
     c->device = device;
@@ -292,7 +397,7 @@ int nbody_ctx_create(nbody_ctx** out, int device)
 int nbody_ctx_destroy(nbody_ctx* c)
 {
     if (!c) return NBODY_OK;
-    (void)hipSetDevice(c->device);
+    DeviceGuard guard(c->device);
     if (c->slabs) (void)hipFree(c->slabs);
     if (c->legacy_buf) (void)hipFree(c->legacy_buf);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
@@ -306,12 +411,17 @@ int nbody_ctx_destroy(nbody_ctx* c)
 int nbody_default_ctx(nbody_ctx** out)
 {
     if (!out) return fail(NBODY_ERR_INVALID, "null out");
-    std::lock_guard<std::mutex> lk(g_default_mu);
-    if (!g_default) {
-        int rc = nbody_ctx_create(&g_default, 0);  // the reference hard-codes device 0 (kernel.cu:630)
+    // The reference never selects a device: its launch goes to the caller's CURRENT device (kernel.cu:630
+    // only queries the properties of device 0). So the default context is the current device's.
+    int device = 0;
+    HIP_TRY(hipGetDevice(&device));
+    if (device < 0 || device >= kMaxDevices) return fail(NBODY_ERR_INVALID, "device %d not supported by the default context", device);
+    std::lock_guard<std::recursive_mutex> lk(g_default_mu);
+    if (!g_default.ctx[device]) {
+        int rc = nbody_ctx_create(&g_default.ctx[device], device);
         if (rc != NBODY_OK) return rc;
     }
-    *out = g_default;
+    *out = g_default.ctx[device];
     return NBODY_OK;
 }
 
@@ -328,7 +438,8 @@ int nbody_ctx_set_params(nbody_ctx* c, float dt, float eps2)
 int nbody_ctx_set_kernel(nbody_ctx* c, int kernel, int tile, int bodies_per_lane, int jsplit)
 {
     if (int rc = check_ctx(c)) return rc;
-    if (kernel != NBODY_KERNEL_FAST && kernel != NBODY_KERNEL_STRICT)
+    if (kernel != NBODY_KERNEL_FAST && kernel != NBODY_KERNEL_STRICT && kernel != NBODY_KERNEL_ONESIDED &&
+        kernel != NBODY_KERNEL_SYMMETRIC)
         return fail(NBODY_ERR_CONFIG, "unknown kernel %d", kernel);
     if (tile != 0 && tile != 256 && tile != 512 && tile != 1024 && tile != 2048)
         return fail(NBODY_ERR_CONFIG, "tile must be 0 (auto), 256, 512, 1024 or 2048 (got %d)", tile);
@@ -344,6 +455,20 @@ int nbody_ctx_set_kernel(nbody_ctx* c, int kernel, int tile, int bodies_per_lane
     return NBODY_OK;
 }
 
+int nbody_ctx_set_symmetric_shape(nbody_ctx* c, int waves, int bodies_per_lane)
+{
+    if (int rc = check_ctx(c)) return rc;
+    bool ok = (waves == 0 && bodies_per_lane == 0);
+    for (int k = 0; k < kSymCands && !ok; ++k)
+        ok = (waves == 0 || waves == kSymCand[k][0]) && (bodies_per_lane == 0 || bodies_per_lane == kSymCand[k][1]);
+    if (!ok)
+        return fail(NBODY_ERR_CONFIG, "symmetric kernel is built for (waves, bodies_per_lane) in {(4,8),(2,8),(2,4),(1,4),(1,2)}; got (%d,%d)",
+                    waves, bodies_per_lane);
+    c->sym_waves = waves;
+    c->sym_bpl = bodies_per_lane;
+    return NBODY_OK;
+}
+
 int nbody_ctx_set_stream(nbody_ctx* c, void* hip_stream)
 {
     if (int rc = check_ctx(c)) return rc;
@@ -355,8 +480,11 @@ int nbody_ctx_reserve(nbody_ctx* c, int n_targets)
 {
     if (int rc = check_ctx(c)) return rc;
     if (n_targets < 0) return fail(NBODY_ERR_INVALID, "n_targets < 0");
-    HIP_TRY(hipSetDevice(c->device));
-    return ensure_slabs(c, (size_t)kMaxSplit * (size_t)n_targets * sizeof(float4));
+    ON_DEVICE(c);
+    SymShape y{};
+    size_t slabs = (size_t)resolve_shape(c, n_targets, n_targets).jsplit;
+    if (sym_wanted(c, n_targets, &y) && (size_t)y.nb > slabs) slabs = (size_t)y.nb;
+    return ensure_slabs(c, slabs * (size_t)n_targets * sizeof(float4));
 }
 
 // Device-free view of the launch-shape logic (host tests; a context needs a GPU, this does not).
@@ -382,10 +510,41 @@ int nbody_ctx_launch_info(nbody_ctx* c, int n_targets, int n_sources, int* jspli
 {
     if (int rc = check_ctx(c)) return rc;
     if (n_targets < 0 || n_sources < 0) return fail(NBODY_ERR_INVALID, "negative size");
+    SymShape y{};
+    if (n_targets == n_sources && sym_wanted(c, n_targets, &y)) {
+        if (jsplit) *jsplit = y.nb;
+        if (blocks) *blocks = y.grid;
+        if (lds_bytes) *lds_bytes = y.block * (int)sizeof(float4);
+        return NBODY_OK;
+    }
     const Shape s = resolve_shape(c, n_targets, n_sources);
     if (jsplit) *jsplit = s.jsplit;
     if (blocks) *blocks = s.blocks_x * s.jsplit;
     if (lds_bytes) *lds_bytes = (c->kernel == NBODY_KERNEL_STRICT ? 1 : 2) * s.tile * (int)sizeof(float4);
+    return NBODY_OK;
+}
+
+int nbody_ctx_step_info(nbody_ctx* c, int n, int* symmetric, int* block_bodies, int* slabs, int* workgroups,
+                        double* evaluated_pairs)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (n < 0) return fail(NBODY_ERR_INVALID, "negative size");
+    SymShape y{};
+    if (sym_wanted(c, n, &y)) {
+        if (symmetric) *symmetric = 1;
+        if (block_bodies) *block_bodies = y.block;
+        if (slabs) *slabs = y.nb;
+        if (workgroups) *workgroups = y.grid;
+        // block pairs I < J once (padded to whole blocks), diagonal blocks both ways
+        if (evaluated_pairs) *evaluated_pairs = ((double)y.nb * (y.nb - 1) / 2 + y.nb) * (double)y.block * (double)y.block;
+        return NBODY_OK;
+    }
+    const Shape s = resolve_shape(c, n, n);
+    if (symmetric) *symmetric = 0;
+    if (block_bodies) *block_bodies = nbk::kWG * s.bpl;
+    if (slabs) *slabs = s.jsplit;
+    if (workgroups) *workgroups = s.blocks_x * s.jsplit;
+    if (evaluated_pairs) *evaluated_pairs = (double)n * (double)n;
     return NBODY_OK;
 }
 
@@ -396,7 +555,30 @@ int accel_impl(nbody_ctx* c, const nbody_float4* d_bodies, nbody_float4* d_acc_o
                int wrap, int accumulate)
 {
     const int nt = i1 - i0;
-    HIP_TRY(hipSetDevice(c->device));
+    ON_DEVICE(c);
+    SymShape y{};
+    if (i0 == j0 && i1 == j1 && sym_wanted(c, nt, &y)) {
+        // a square block (targets == sources): every unordered pair once
+        if (int rc = ensure_slabs(c, (size_t)y.nb * nt * sizeof(float4))) return rc;
+        nbk::SymParams sp{};
+        sp.x = reinterpret_cast<const float4*>(d_bodies) + i0;
+        sp.slabs = static_cast<float4*>(c->slabs);
+        sp.n = nt;
+        sp.nb = y.nb;
+        sp.stride = nt;
+        sp.eps2 = c->eps2;
+        if (int rc = launch_sym(c, y, sp)) return rc;
+        nbk::ReduceParams r{};
+        r.out = reinterpret_cast<float4*>(d_acc_out);
+        r.slabs = static_cast<const float4*>(c->slabs);
+        r.nslab = y.nb;
+        r.slab_stride = nt;
+        r.n = nt;
+        r.accumulate = accumulate ? 1 : 0;
+        nbk::reduce_slabs<<<(nt + nbk::kWG - 1) / nbk::kWG, nbk::kWG, 0, c->stream>>>(r);
+        HIP_TRY(hipGetLastError());
+        return NBODY_OK;
+    }
     const Shape s = resolve_shape(c, nt, j1 - j0);
     nbk::ForceParams p{};
     p.x = reinterpret_cast<const float4*>(d_bodies);
@@ -461,7 +643,7 @@ int nbody_integrate_range(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_
     const int n = i1 - i0;
     if (n == 0) return NBODY_OK;
     if (!d_bodies || !d_velocity || !d_acc) return fail(NBODY_ERR_INVALID, "null device pointer");
-    HIP_TRY(hipSetDevice(c->device));
+    ON_DEVICE(c);
     nbk::IntegrateParams q{};
     q.x = reinterpret_cast<float4*>(d_bodies) + i0;
     q.v = reinterpret_cast<float4*>(d_velocity);
@@ -483,62 +665,94 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
     if (n < 0 || steps < 0) return fail(NBODY_ERR_INVALID, "n=%d steps=%d", n, steps);
     if (n == 0 || steps == 0) return NBODY_OK;  // an empty system is a no-op, whatever the pointers
     if (!d_bodies || !d_accelerations || !d_velocity) return fail(NBODY_ERR_INVALID, "null device pointer");
-    HIP_TRY(hipSetDevice(c->device));
+    ON_DEVICE(c);
+    SymShape y{};
+    const bool sym = sym_wanted(c, n, &y);
     const Shape s = resolve_shape(c, n, n);
     nbk::ForceParams p{};
-    p.x = reinterpret_cast<const float4*>(d_bodies);
-    p.i0 = 0; p.i1 = n; p.j0 = 0; p.j1 = n;
-    p.eps2 = c->eps2;
-    p.accumulate = 0;
+    nbk::SymParams sp{};
     nbk::IntegrateParams q{};
     q.x = reinterpret_cast<float4*>(d_bodies);
     q.v = reinterpret_cast<float4*>(d_velocity);
     q.a = reinterpret_cast<float4*>(d_accelerations);
     q.n = n;
     q.dt = c->dt;
-    if (s.jsplit == 1) {
-        p.out = q.a;
-        p.slab_stride = 0;
-        q.slabs = nullptr;
-        q.nslab = 0;
-        q.slab_stride = 0;
-    } else {
-        if (int rc = ensure_slabs(c, (size_t)s.jsplit * n * sizeof(float4))) return rc;
-        p.out = static_cast<float4*>(c->slabs);
-        p.slab_stride = n;
+    if (sym) {
+        if (int rc = ensure_slabs(c, (size_t)y.nb * n * sizeof(float4))) return rc;
+        sp.x = reinterpret_cast<const float4*>(d_bodies);
+        sp.slabs = static_cast<float4*>(c->slabs);
+        sp.n = n;
+        sp.nb = y.nb;
+        sp.stride = n;
+        sp.eps2 = c->eps2;
         q.slabs = static_cast<const float4*>(c->slabs);
-        q.nslab = s.jsplit;
+        q.nslab = y.nb;
         q.slab_stride = n;
+    } else {
+        p.x = reinterpret_cast<const float4*>(d_bodies);
+        p.i0 = 0; p.i1 = n; p.j0 = 0; p.j1 = n;
+        p.eps2 = c->eps2;
+        p.accumulate = 0;
+        if (s.jsplit == 1) {
+            p.out = q.a;
+            p.slab_stride = 0;
+            q.slabs = nullptr;
+            q.nslab = 0;
+            q.slab_stride = 0;
+        } else {
+            if (int rc = ensure_slabs(c, (size_t)s.jsplit * n * sizeof(float4))) return rc;
+            p.out = static_cast<float4*>(c->slabs);
+            p.slab_stride = n;
+            q.slabs = static_cast<const float4*>(c->slabs);
+            q.nslab = s.jsplit;
+            q.slab_stride = n;
+        }
     }
     const int iblocks = (n + nbk::kWG - 1) / nbk::kWG;
+    // one step = one force launch + one integrate launch, both checked
+    auto enqueue_step = [&](bool timed) -> int {
+        int rc;
+        if (sym) rc = timed ? launch_sym(c, y, sp) : launch_sym_untimed(c, y, sp);
+        else rc = timed ? launch_force(c, s, p) : launch_force_untimed(c, s, p);
+        if (rc != NBODY_OK) return rc;
+        nbk::integrate<<<iblocks, nbk::kWG, 0, c->stream>>>(q);
+        HIP_TRY(hipGetLastError());
+        return NBODY_OK;
+    };
     int k = 0;
     const bool graphable = !c->timing && (c->use_graph == 1 || (c->use_graph < 0 && n <= kGraphMaxN));
     if (graphable && steps >= kGraphChunk) {
         // Launch-bound regime: replay a captured chain of kGraphChunk steps instead of 2*kGraphChunk
         // host launches. The kernels and their order are exactly those of the loop below.
-        const nbody_ctx::GraphKey key{p.x, q.a, q.v, c->slabs, n, s.bpl, s.tile, s.jsplit, c->kernel, kGraphChunk, c->dt, c->eps2, c->stream};
+        const nbody_ctx::GraphKey key{d_bodies, q.a, q.v, c->slabs, n, sym ? y.bpl : s.bpl, sym ? y.waves : s.tile,
+                                      sym ? y.nb : s.jsplit, c->kernel, kGraphChunk, c->dt, c->eps2, c->stream};
         if (!c->graph_exec || !(key == c->graph_key)) {
             if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
             if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
             HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
             int rc = NBODY_OK;
-            for (int g = 0; g < kGraphChunk && rc == NBODY_OK; ++g) {
-                rc = launch_force_untimed(c, s, p);
-                nbk::integrate<<<iblocks, nbk::kWG, 0, c->stream>>>(q);
+            for (int g = 0; g < kGraphChunk && rc == NBODY_OK; ++g) rc = enqueue_step(false);
+            hipGraph_t captured = nullptr;
+            const hipError_t ce = hipStreamEndCapture(c->stream, &captured);  // always end the capture
+            if (rc != NBODY_OK || ce != hipSuccess) {
+                if (captured) (void)hipGraphDestroy(captured);  // a partial graph is never kept
+                if (rc != NBODY_OK) return rc;
+                return fail(NBODY_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
             }
-            hipError_t ce = hipStreamEndCapture(c->stream, &c->graph);
-            if (rc != NBODY_OK) return rc;
-            if (ce != hipSuccess) return fail(NBODY_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
-            HIP_TRY(hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
+            c->graph = captured;
+            const hipError_t ie = hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0);
+            if (ie != hipSuccess) {
+                (void)hipGraphDestroy(c->graph);
+                c->graph = nullptr;
+                c->graph_exec = nullptr;
+                return fail(NBODY_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+            }
             c->graph_key = key;
         }
         for (; k + kGraphChunk <= steps; k += kGraphChunk) HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
     }
-    for (; k < steps; ++k) {
-        if (int rc = launch_force(c, s, p)) return rc;
-        nbk::integrate<<<iblocks, nbk::kWG, 0, c->stream>>>(q);
-    }
-    HIP_TRY(hipGetLastError());
+    for (; k < steps; ++k)
+        if (int rc = enqueue_step(true)) return rc;
     return NBODY_OK;
 }
 
@@ -584,6 +798,7 @@ int nbody_ctx_sync(nbody_ctx* c)
 
 int nbody_simulate(nbody_float4* d_bodies, nbody_float4* d_accelerations, nbody_float4* d_velocity, int n)
 {
+    std::lock_guard<std::recursive_mutex> lk(g_default_mu);
     nbody_ctx* c = nullptr;
     if (int rc = nbody_default_ctx(&c)) return rc;
     if (int rc = nbody_step(c, d_bodies, d_accelerations, d_velocity, n, 1)) return rc;
@@ -597,12 +812,13 @@ int nbody_simulate(nbody_float4* d_bodies, nbody_float4* d_accelerations, nbody_
 // instead of being re-allocated (and leaked) per call as the original does (kernel.cu:94-96).
 int nbody_simulate_host_legacy(nbody_float4* h_bodies, nbody_float3* h_accelerations, nbody_float3* h_velocity, int n)
 {
+    std::lock_guard<std::recursive_mutex> lk(g_default_mu);  // eps2 / legacy_eps of the shared context are switched below
     nbody_ctx* c = nullptr;
     if (int rc = nbody_default_ctx(&c)) return rc;
     if (n < 0) return fail(NBODY_ERR_INVALID, "n=%d", n);
     if (n == 0) return NBODY_OK;
     if (!h_bodies || !h_accelerations || !h_velocity) return fail(NBODY_ERR_INVALID, "null host pointer");
-    HIP_TRY(hipSetDevice(c->device));
+    ON_DEVICE(c);
     const size_t size4 = sizeof(float4) * (size_t)n, size3 = 3 * sizeof(float) * (size_t)n;
     const size_t need = size4 + 2 * size3 + 64;
     if (need > c->legacy_bytes) {
@@ -664,7 +880,7 @@ int nbody_step_f64(nbody_ctx* c, nbody_double4* d_bodies, nbody_double4* d_accel
     if (n < 0 || steps < 0) return fail(NBODY_ERR_INVALID, "n=%d steps=%d", n, steps);
     if (!(eps2 > 0.0)) return fail(NBODY_ERR_INVALID, "eps2 must be > 0");
     if (n == 0 || steps == 0) return NBODY_OK;
-    HIP_TRY(hipSetDevice(c->device));
+    ON_DEVICE(c);
     constexpr int BPL = 2, TILE = 512;
     const int blocks_x = (n + nbk::kWG * BPL - 1) / (nbk::kWG * BPL);
     int js = c->jsplit;
@@ -691,10 +907,13 @@ int nbody_step_f64(nbody_ctx* c, nbody_double4* d_bodies, nbody_double4* d_accel
     q.n = n;
     q.dt = dt;
     for (int k = 0; k < steps; ++k) {
+        if (int rc = time_mark(c)) return rc;
         nbk::force_f64<BPL, TILE><<<dim3(blocks_x, js), nbk::kWG, 0, c->stream>>>(p);
+        HIP_TRY(hipGetLastError());
+        if (int rc = time_mark(c)) return rc;
         nbk::integrate_f64<<<(n + nbk::kWG - 1) / nbk::kWG, nbk::kWG, 0, c->stream>>>(q);
+        HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipGetLastError());
     return NBODY_OK;
 }
 

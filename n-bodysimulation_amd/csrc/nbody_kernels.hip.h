@@ -354,30 +354,40 @@ struct SymPacked {
     {
         const f32x2 bx = {sx, sx}, by = {sy, sy}, bz = {sz, sz}, bm = {sm, sm};
         f32x2 ux = {0.0f, 0.0f}, uy = {0.0f, 0.0f}, uz = {0.0f, 0.0f};
+        // written stage by stage across the H register pairs: dependent packed ops of one pair are
+        // then H instructions apart (back-to-back dependent v_pk_* cost an s_nop each on gfx950)
+        f32x2 rx[H], ry[H], rz[H], d[H], w[H], fi[H];
+#pragma unroll
+        for (int k = 0; k < H; ++k) { rx[k] = bx - x[k]; ry[k] = by - y[k]; rz[k] = bz - z[k]; }
+#pragma unroll
+        for (int k = 0; k < H; ++k) d[k] = __builtin_elementwise_fma(rx[k], rx[k], e2);
+#pragma unroll
+        for (int k = 0; k < H; ++k) d[k] = __builtin_elementwise_fma(ry[k], ry[k], d[k]);
+#pragma unroll
+        for (int k = 0; k < H; ++k) d[k] = __builtin_elementwise_fma(rz[k], rz[k], d[k]);
+#pragma unroll
+        for (int k = 0; k < H; ++k) { w[k].x = __builtin_amdgcn_rsqf(d[k].x); w[k].y = __builtin_amdgcn_rsqf(d[k].y); }
+#pragma unroll
+        for (int k = 0; k < H; ++k) d[k] = w[k] * w[k];
+#pragma unroll
+        for (int k = 0; k < H; ++k) w[k] = d[k] * w[k];
+#pragma unroll
+        for (int k = 0; k < H; ++k) fi[k] = bm * w[k];
 #pragma unroll
         for (int k = 0; k < H; ++k) {
-            const f32x2 rx = bx - x[k];
-            const f32x2 ry = by - y[k];
-            const f32x2 rz = bz - z[k];
-            f32x2 d = __builtin_elementwise_fma(rx, rx, e2);
-            d = __builtin_elementwise_fma(ry, ry, d);
-            d = __builtin_elementwise_fma(rz, rz, d);
-            f32x2 inv;
-            inv.x = __builtin_amdgcn_rsqf(d.x);
-            inv.y = __builtin_amdgcn_rsqf(d.y);
-            const f32x2 w = inv * inv * inv;
-            const f32x2 fi = bm * w;
-            ax[k] = __builtin_elementwise_fma(rx, fi, ax[k]);
-            ay[k] = __builtin_elementwise_fma(ry, fi, ay[k]);
-            az[k] = __builtin_elementwise_fma(rz, fi, az[k]);
-            if (SYM) {
-                const f32x2 fj = m[k] * w;
-                if (k == 0) { ux = rx * fj; uy = ry * fj; uz = rz * fj; }
-                else {
-                    ux = __builtin_elementwise_fma(rx, fj, ux);
-                    uy = __builtin_elementwise_fma(ry, fj, uy);
-                    uz = __builtin_elementwise_fma(rz, fj, uz);
-                }
+            ax[k] = __builtin_elementwise_fma(rx[k], fi[k], ax[k]);
+            ay[k] = __builtin_elementwise_fma(ry[k], fi[k], ay[k]);
+            az[k] = __builtin_elementwise_fma(rz[k], fi[k], az[k]);
+        }
+        if (SYM) {
+#pragma unroll
+            for (int k = 0; k < H; ++k) fi[k] = m[k] * w[k];
+            ux = rx[0] * fi[0]; uy = ry[0] * fi[0]; uz = rz[0] * fi[0];
+#pragma unroll
+            for (int k = 1; k < H; ++k) {
+                ux = __builtin_elementwise_fma(rx[k], fi[k], ux);
+                uy = __builtin_elementwise_fma(ry[k], fi[k], uy);
+                uz = __builtin_elementwise_fma(rz[k], fi[k], uz);
             }
         }
         tx = ux.x + ux.y; ty = uy.x + uy.y; tz = uz.x + uz.y;
@@ -465,8 +475,8 @@ __device__ __forceinline__ float next_row(const float v, const int addr)
 __device__ __forceinline__ int sym_row_offset(int I, int nb) { return (int)(((long)I * (2L * nb - I - 1)) / 2); }
 
 // grid = nb*(nb-1)/2 pair tasks followed by nb diagonal tasks; block = 64*W threads.
-template <class M, int W>
-__global__ void __launch_bounds__(64 * W) force_sym(const SymParams p)
+template <class M, int W, int MINW = 1>
+__global__ void __launch_bounds__(64 * W, MINW) force_sym(const SymParams p)
 {
     constexpr int BPL = M::BPL;
     constexpr int B = 64 * W * BPL;
@@ -520,7 +530,7 @@ __global__ void __launch_bounds__(64 * W) force_sym(const SymParams p)
         const int cn = (c + 1 == NCH) ? 0 : c + 1;
         if (q + 1 < NCH) nxt = fetch(cn);
         if (diag) {
-            float4 aj;
+            float4 aj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             for (int ph = 0; ph < 4; ++ph) {
                 sym_row_pass<false>(t, bj, aj);
                 bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot); bj.w = next_row(bj.w, rot);
@@ -642,6 +652,8 @@ __global__ void __launch_bounds__(kWG) integrate(const IntegrateParams p)
     float4 a;
     if (p.nslab > 0) {
         a = p.slabs[i];
+        // the sum is taken in slab order whatever the unrolling: only the loads are batched
+#pragma unroll 8
         for (int s = 1; s < p.nslab; ++s) {
             const float4 q = p.slabs[(size_t)s * p.slab_stride + i];
             a.x += q.x; a.y += q.y; a.z += q.z;
@@ -716,6 +728,7 @@ __global__ void __launch_bounds__(kWG) reduce_slabs(const ReduceParams p)
     const int i = blockIdx.x * kWG + threadIdx.x;
     if (i >= p.n) return;
     float4 a = p.accumulate ? p.out[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll 8
     for (int s = 0; s < p.nslab; ++s) {
         const float4 q = p.slabs[(size_t)s * p.slab_stride + i];
         a.x += q.x; a.y += q.y; a.z += q.z;

@@ -88,6 +88,10 @@ class Context:
         check(self._lib.nbody_ctx_set_kernel(self._h, kernel, tile, bodies_per_lane, jsplit))
         self.kernel = kernel
 
+    def set_symmetric_shape(self, waves: int = 0, bodies_per_lane: int = 0) -> None:
+        """Block shape of the symmetric kernel (64*waves*bodies_per_lane bodies per block); 0 = auto."""
+        check(self._lib.nbody_ctx_set_symmetric_shape(self._h, waves, bodies_per_lane))
+
     def set_stream(self, stream: Optional[torch.cuda.Stream]) -> None:
         self._stream = stream  # keep it alive
         check(self._lib.nbody_ctx_set_stream(self._h, C.c_void_p(stream.cuda_stream) if stream is not None else None))
@@ -103,6 +107,13 @@ class Context:
         js, bl, lds = C.c_int(), C.c_int(), C.c_int()
         check(self._lib.nbody_ctx_launch_info(self._h, n_targets, n_sources, C.byref(js), C.byref(bl), C.byref(lds)))
         return {"jsplit": js.value, "blocks": bl.value, "lds_bytes": lds.value}
+
+    def step_info(self, n: int) -> dict:
+        """What a whole step of n bodies launches (symmetric or one-sided kernel, slabs, pair evaluations)."""
+        sym, blk, slabs, wgs, ev = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_double()
+        check(self._lib.nbody_ctx_step_info(self._h, n, C.byref(sym), C.byref(blk), C.byref(slabs), C.byref(wgs), C.byref(ev)))
+        return {"symmetric": bool(sym.value), "block_bodies": blk.value, "slabs": slabs.value,
+                "workgroups": wgs.value, "evaluated_pairs": ev.value}
 
     def step(self, x: torch.Tensor, a: torch.Tensor, v: torch.Tensor, steps: int = 1) -> None:
         n = x.shape[0]

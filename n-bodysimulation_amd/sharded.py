@@ -123,6 +123,11 @@ class HipBackend:
         return {"steps": len(gather), "all_gather_ms_avg": sum(gather) / len(gather),
                 "exposed_ms_avg": sum(exposed) / len(exposed)}
 
+    def ready(self) -> None:
+        """Allocation/upload barrier: tensors were filled on torch's current stream, kernels run on
+        self.compute / self.comm, which do not synchronise with it implicitly."""
+        torch.cuda.synchronize(self.device)
+
     def mark_integrated(self) -> None:
         self._integrated.record(self.compute)
 
@@ -165,6 +170,11 @@ class ShardedSimulation:
         self.v = backend.empty(self.shard)
         self.a = backend.empty(self.shard)
         self._fresh = True                           # X_full already consistent: skip first gather
+        # the uploads and zero fills above ran on the allocating stream: finish them before the first
+        # kernel on the backend's own (non-blocking) streams reads or overwrites those arrays
+        ready = getattr(backend, "ready", None)
+        if ready is not None:
+            ready()
         backend.mark_integrated()
 
     def step(self, steps: int = 1) -> None:

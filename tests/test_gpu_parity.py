@@ -98,7 +98,8 @@ def test_fast_single_step_vs_literal_reference(nb, oracle):
     amax = np.abs(g["a_1"][:, :3]).max()
     ordering = np.abs(aj - g["a_1"])[:, :3]                        # in-place vs Jacobi, per component
     assert np.all(np.abs(a - g["a_1"])[:, :3] <= ordering + 1e-5 * amax)
-    assert np.array_equal(a[0], a[0]) and np.abs(a[0] - g["a_1"][0])[:3].max() <= 1e-5 * amax  # body 0: no ordering effect
+    # body 0 is processed first by the in-place loop, so it sees no ordering effect at all
+    assert np.all(ordering[0] == 0) and np.abs(a[0] - g["a_1"][0])[:3].max() <= 1e-5 * amax
 
 
 @pytest.mark.parametrize("opts", [dict(tile=256, bodies_per_lane=1, jsplit=1), dict(tile=512, bodies_per_lane=2, jsplit=2),
@@ -110,6 +111,102 @@ def test_fast_kernel_configurations_agree(nb, oracle, opts):
     ao = oracle.accel_range(x0, 0, n, eps2=0.002)
     x, v, a = _gpu_run(nb, x0, 1, 0.01, 0.002, nb.KERNEL_FAST, **opts)
     assert np.abs(a - ao)[:, :3].max() / np.abs(ao[:, :3]).max() <= 1e-5
+
+
+# ---- the symmetric kernel (every unordered pair once) -----------------------------------------------
+
+@pytest.mark.parametrize("waves,bpl", [(1, 2), (1, 4), (2, 4), (2, 8), (4, 8)])
+@pytest.mark.parametrize("n,init", [(1000, 0), (4099, 1), (6144, 0)])
+def test_symmetric_kernel_shapes_vs_oracle(nb, oracle, waves, bpl, n, init):
+    """Every block shape the library builds, on sizes that are not multiples of the block (the last
+    block is padded with massless bodies) and on one that is: accelerations against the fp64-accumulated
+    CPU sum, momentum balance, w = 0, and agreement with the one-sided kernel."""
+    block = 64 * waves * bpl
+    x0 = nb.engine.seeded_bodies(n, init, 7)
+    ctx = nb.engine.Context(kernel=nb.KERNEL_SYMMETRIC)
+    ctx.set_symmetric_shape(waves, bpl)
+    info = ctx.step_info(n)
+    nblk = -(-n // block)
+    if nblk >= 2:
+        assert info["symmetric"] and info["block_bodies"] == block and info["slabs"] == nblk
+        assert info["workgroups"] == nblk * (nblk + 1) // 2
+        assert info["evaluated_pairs"] == info["workgroups"] * block * block
+    else:
+        assert not info["symmetric"]                 # a single block: nothing to pair up, one-sided kernel
+    x = torch.from_numpy(x0).cuda()
+    a = torch.full((n, 4), 3.0, device="cuda")
+    ctx.accel_range(x, a, 0, n, 0, n)
+    ctx.sync()
+    ag = a.cpu().numpy()
+    truth = oracle.accel_range(x0, 0, n, eps2=0.002, f64acc=True)
+    amax = np.abs(truth[:, :3]).max()
+    assert np.abs(ag - truth)[:, :3].max() / amax <= 1e-5
+    assert np.all(ag[:, 3] == 0)
+    m = x0[:, 3:4].astype(np.float64)
+    assert np.abs((m * ag[:, :3]).sum(0)).max() / (m * np.abs(ag[:, :3])).sum() < 1e-6
+    one = nb.engine.Context(kernel=nb.KERNEL_ONESIDED)
+    a1 = torch.zeros_like(a)
+    one.accel_range(x, a1, 0, n, 0, n)
+    one.sync()
+    assert np.abs(ag - a1.cpu().numpy())[:, :3].max() / amax <= 1e-5
+    # accumulate continues a sum already in the output
+    ctx.accel_range(x, a, 0, n, 0, n, accumulate=True)
+    ctx.sync()
+    assert np.abs(a.cpu().numpy() - 2 * ag)[:, :3].max() / amax <= 1e-6
+
+
+def test_symmetric_step_trajectory_and_determinism(nb, oracle):
+    """Whole steps through nbody_step with the symmetric kernel forced at a size the oracle finishes:
+    K=10 steps vs the Jacobi oracle, bitwise run-to-run reproducibility, integrate bit-exact."""
+    g = load_golden("jacobi_plummer_n1024_dt0.01.npz")
+    runs = []
+    for _ in range(2):
+        sim = nb.engine.Simulation(g["x0"], dt=0.01, eps2=0.002, kernel=nb.KERNEL_SYMMETRIC)
+        sim.ctx.set_symmetric_shape(1, 2)
+        assert sim.ctx.step_info(1024)["symmetric"]
+        sim.run(9)
+        x9, v9, _ = sim.state()
+        sim.run(1)
+        runs.append(sim.state())
+    x, v, a = runs[0]
+    assert np.abs(x - g["x_10"])[:, :3].max() <= 2e-6
+    assert all(np.array_equal(p, q) for p, q in zip(runs[0], runs[1]))
+    xs, vs = x9.copy(), v9.copy()
+    oracle.integrate(xs, vs, a, dt=0.01)
+    assert same_bits(xs, x) and same_bits(vs, v)
+
+
+def test_symmetric_vs_onesided_at_n65536(nb, oracle):
+    """configs[1]'s size: FAST picks the symmetric kernel; it agrees with the one-sided kernel to a few
+    ulp of max|a| and is at least as close to the fp64 truth on sampled targets."""
+    n = 65536
+    x0 = nb.engine.seeded_bodies(n, 0, 515)        # the reference's cube and mass range
+    x = torch.from_numpy(x0).cuda()
+    out = {}
+    for name, k in (("fast", nb.KERNEL_FAST), ("one", nb.KERNEL_ONESIDED)):
+        ctx = nb.engine.Context(kernel=k)
+        assert ctx.step_info(n)["symmetric"] == (name == "fast")
+        a = torch.zeros_like(x)
+        ctx.accel_range(x, a, 0, n, 0, n)
+        ctx.sync()
+        out[name] = a.cpu().numpy()
+    truth = oracle.accel_range(x0, 5000, 5512, 0, n, eps2=0.002, f64acc=True)
+    amax = np.abs(truth[:, :3]).max()
+    e_sym = np.abs(out["fast"][5000:5512] - truth)[:, :3].max() / amax
+    e_one = np.abs(out["one"][5000:5512] - truth)[:, :3].max() / amax
+    assert e_sym <= 1e-5 and e_one <= 1e-5
+    an = np.abs(out["one"][:, :3]).max()
+    assert np.abs(out["fast"] - out["one"])[:, :3].max() / an <= 2e-5
+
+
+def test_symmetric_shape_errors(nb):
+    ctx = nb.engine.Context()
+    with pytest.raises(nb.NBodyError):
+        ctx.set_symmetric_shape(3, 8)
+    with pytest.raises(nb.NBodyError):
+        ctx.set_symmetric_shape(4, 2)
+    ctx.set_symmetric_shape(0, 8)
+    ctx.set_symmetric_shape(0, 0)
 
 
 # ---- T3 / T4: trajectories -------------------------------------------------------------------------
@@ -154,6 +251,7 @@ def test_simulate_dropin(nb, oracle):
     assert np.abs(xg[:n] - xo)[:, :3].max() / 1e5 <= 1e-6
     assert np.abs(ag[:n] - ao)[:, :3].max() / np.abs(ao[:, :3]).max() <= 1e-5
     assert np.array_equal(xg[n:], x0[n:]) and np.all(ag[n:] == 7.0) and np.all(vg[n:] == 0)  # tail untouched
+    assert torch.cuda.current_device() == dev.index                 # the caller's device is left as it was
 
 
 def test_error_paths(nb):
@@ -164,6 +262,9 @@ def test_error_paths(nb):
         ctx.set_kernel(nb.KERNEL_FAST, tile=100)
     with pytest.raises(nb.NBodyError):
         ctx.set_kernel(7)
+    ctx.set_kernel(nb.KERNEL_ONESIDED)
+    ctx.set_kernel(nb.KERNEL_SYMMETRIC)
+    ctx.set_kernel(nb.KERNEL_FAST)
     x = torch.zeros((8, 4), device="cuda")
     with pytest.raises(ValueError):
         ctx.step(x, x[:4], x)
