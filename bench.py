@@ -57,6 +57,18 @@ def weak_n(gpus: int) -> int:
     return int(round(N_SINGLE * math.sqrt(gpus) / q)) * q
 
 
+def default_workload(world: int, bodies: int, scaling: str):
+    """(N, scaling label) for a run on `world` GPUs: BASELINE.json configs[2] on one GPU, configs[3] strong-scaled on
+    several, unless --bodies / --scaling weak say otherwise."""
+    if bodies:
+        return bodies, ("strong" if world > 1 else "weak")
+    if world == 1:
+        return N_SINGLE, "weak"
+    if scaling == "weak":
+        return weak_n(world), "weak"
+    return N_MULTI, "strong"
+
+
 def ensure_built() -> None:
     """Build the in-tree binaries if a snapshot lacks them — under an exclusive file lock, so that with
     several ranks starting at once exactly one compiles and the others wait for the finished library
@@ -192,14 +204,7 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    if args.n:
-        n, scaling = args.n, ("strong" if world > 1 else "weak")
-    elif world == 1:
-        n, scaling = N_SINGLE, "weak"
-    elif args.scaling == "weak":
-        n, scaling = weak_n(world), "weak"
-    else:
-        n, scaling = N_MULTI, "strong"
+    n, scaling = default_workload(world, args.n, args.scaling)
     x0 = nbody_amd.engine.seeded_bodies(n, args.init, 12345)
     kernel = {"fast": nbody_amd.KERNEL_FAST, "onesided": nbody_amd.KERNEL_ONESIDED, "symmetric": nbody_amd.KERNEL_SYMMETRIC}[args.kernel]
     kopts = dict(kernel=kernel, tile=args.tile, bodies_per_lane=args.bpl, jsplit=args.jsplit)

@@ -183,6 +183,13 @@ int nbody_device_synchronize(void);                    /* cudaDeviceSynchronize 
 void nbody_fill_with_random4(nbody_float4* h_v, int n);
 /* utils.cpp:19-27 */
 void nbody_fill_with_zeroes4(nbody_float4* h_v, int n);
+/* utils.cpp:6 — ((float)rand() / RAND_MAX) * (max - min) + min, one libc rand() draw */
+float nbody_random_float(float min, float max);
+/* utils.cpp:9-16 */
+void nbody_fill_with_zeroes3(nbody_float3* h_v, int n);
+/* utils.cpp:50-68: the reference prints cudaDeviceProp fields of device 0; this prints the same lines
+ * from hipDeviceProp_t of the CURRENT device (returns NBODY_ERR_HIP when there is none). */
+int nbody_print_device_prop(void);
 /* Portable, seeded generators for reproducible cross-machine inputs (libc rand() is not:
  * RAND_MAX differs between libcs). init: 0 = the reference's uniform cube and mass range,
  * 1 = Plummer sphere (a = 1, total mass 1, G = 1), cold start. */
@@ -191,6 +198,8 @@ int nbody_fill_seeded(nbody_float4* h_bodies, int n, int init, unsigned long lon
  * printed "Problem at body" for instead of printing them. */
 int nbody_verify_still_bodies(const nbody_float4* h_v, const nbody_float4* h_x, int n);
 int nbody_verify_equality4(const nbody_float4* h_v, const nbody_float4* h_x, int n);
+/* validation.cpp:125-140 (x, y, z only) */
+int nbody_verify_equality3(const nbody_float3* h_v, const nbody_float3* h_x, int n);
 
 /* ---- measurement ------------------------------------------------------------------------- */
 /* With timing on, every force-kernel launch made through this context is bracketed by a pair of

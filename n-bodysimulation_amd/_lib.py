@@ -68,6 +68,10 @@ _SIGNATURES = {
     "nbody_device_synchronize": (C.c_int, []),
     "nbody_fill_with_random4": (None, [_p, C.c_int]),
     "nbody_fill_with_zeroes4": (None, [_p, C.c_int]),
+    "nbody_fill_with_zeroes3": (None, [_p, C.c_int]),
+    "nbody_random_float": (C.c_float, [C.c_float, C.c_float]),
+    "nbody_print_device_prop": (C.c_int, []),
+    "nbody_verify_equality3": (C.c_int, [_p, _p, C.c_int]),
     "nbody_fill_seeded": (C.c_int, [_p, C.c_int, C.c_int, C.c_ulonglong]),
     "nbody_verify_still_bodies": (C.c_int, [_p, _p, C.c_int]),
     "nbody_verify_equality4": (C.c_int, [_p, _p, C.c_int]),

@@ -917,6 +917,33 @@ int nbody_step_f64(nbody_ctx* c, nbody_double4* d_bodies, nbody_double4* d_accel
     return NBODY_OK;
 }
 
+// utils.cpp:50-68 — the same lines, from hipDeviceProp_t of the current device (the reference reads device 0's
+// cudaDeviceProp; "Warp size" prints the 64-lane wavefront here)
+int nbody_print_device_prop(void)
+{
+    int device = 0;
+    HIP_TRY(hipGetDevice(&device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    printf("== Device Properties ==\n");
+    printf("Name: %s\n", prop.name);
+    printf("Total global memory: %llu\n", (unsigned long long)prop.totalGlobalMem);
+    printf("Total shared memory: %llu\n", (unsigned long long)prop.multiProcessorCount * (unsigned long long)prop.maxSharedMemoryPerMultiProcessor);
+    printf("Multiprocessors count: %d\n", prop.multiProcessorCount);
+    printf("Shared memory per multiprocessor: %llu\n", (unsigned long long)prop.maxSharedMemoryPerMultiProcessor);
+    printf("Shared memory per block: %llu\n", (unsigned long long)prop.sharedMemPerBlock);
+    printf("Registers per block: %d\n", prop.regsPerBlock);
+    printf("Registers per multiprocessor: %d\n", prop.regsPerMultiprocessor);
+    printf("Max (parallel) blocks per multiprocessor: %d\n", prop.maxBlocksPerMultiProcessor);
+    printf("Max (parallel) threads per multiprocessor: %d\n", prop.maxThreadsPerMultiProcessor);
+    printf("Max grid size: (%d, %d, %d)\n", prop.maxGridSize[0], prop.maxGridSize[1], prop.maxGridSize[2]);
+    printf("Max threads per block: %d\n", prop.maxThreadsPerBlock);
+    printf("Warp size: %d\n", prop.warpSize);
+    printf("\n");
+    fflush(stdout);
+    return NBODY_OK;
+}
+
 // ---- memory helpers ---------------------------------------------------------------------
 
 int nbody_malloc_device(void** d_ptr, size_t bytes)

@@ -41,6 +41,19 @@ void nbody_fill_with_random4(nbody_float4* v, int n)
     }
 }
 
+// utils.cpp:6
+float nbody_random_float(float lo, float hi) { return random_float(lo, hi); }
+
+// utils.cpp:9-16
+void nbody_fill_with_zeroes3(nbody_float3* v, int n)
+{
+    for (int i = 0; i < n; ++i) {
+        v[i].x = 0.0f;
+        v[i].y = 0.0f;
+        v[i].z = 0.0f;
+    }
+}
+
 // utils.cpp:19-27
 void nbody_fill_with_zeroes4(nbody_float4* v, int n)
 {
@@ -103,6 +116,17 @@ int nbody_verify_still_bodies(const nbody_float4* v, const nbody_float4* x, int 
         const float dy = std::fabs(v[i].y - x[i].y);
         const float dz = std::fabs(v[i].z - x[i].z);
         if (dx > tx || dy > ty || dz > tz) ++bad;
+    }
+    return bad;
+}
+
+// validation.cpp:125-140 as a count
+int nbody_verify_equality3(const nbody_float3* v, const nbody_float3* x, int n)
+{
+    const float tol = 0.01;
+    int bad = 0;
+    for (int i = 0; i < n; ++i) {
+        if (std::fabs(v[i].x - x[i].x) > tol || std::fabs(v[i].y - x[i].y) > tol || std::fabs(v[i].z - x[i].z) > tol) ++bad;
     }
     return bad;
 }

@@ -234,6 +234,26 @@ void oracle_step_jacobi_f64(odouble4 *X, odouble4 *A, odouble4 *V, int n, double
     }
 }
 
+/* Accelerations only, all-double: targets [i0,i1) against sources [j0,j1), j == i skipped. Same pair
+ * expression as oracle_step_jacobi_f64 (the checker of the build's own fp64 kernel at sizes where a
+ * whole CPU step would take minutes: sampled targets against all sources). */
+void oracle_accel_range_f64(const odouble4 *X, odouble4 *A_out, int i0, int i1, int j0, int j1, double eps2)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = i0; i < i1; ++i) {
+        const double xi = X[i].x, yi = X[i].y, zi = X[i].z;
+        double ax = 0.0, ay = 0.0, az = 0.0;
+        for (int j = j0; j < j1; ++j) {
+            if (j == i) continue;
+            double rx = X[j].x - xi, ry = X[j].y - yi, rz = X[j].z - zi;
+            double d = rx * rx + ry * ry + rz * rz + eps2;
+            double s = X[j].w * (1.0 / sqrt(d * d * d));
+            ax += rx * s; ay += ry * s; az += rz * s;
+        }
+        A_out[i - i0].x = ax; A_out[i - i0].y = ay; A_out[i - i0].z = az; A_out[i - i0].w = 0.0;
+    }
+}
+
 /* The OLDER snapshot's step (Sim-Without-OpenGL-Integration/kernel.cu:5-25,38-82 with its
  * constants.h:14-15, `EPS2 0.002` and `DT 0.01` as DOUBLE literals), in Jacobi order: the float sum
  * r.r is promoted to double for `+ EPS2`; `gV + 0.5 * DT * a` and `gX + DT * gV` are evaluated in

@@ -50,6 +50,7 @@ void oracle_integrate(ofloat4 *X, ofloat4 *V, const ofloat4 *A, int n, float dt)
 
 /* All-double state (the build's own fp64 variant; no reference analogue). */
 void oracle_step_jacobi_f64(odouble4 *X, odouble4 *A, odouble4 *V, int n, double dt, double eps2);
+void oracle_accel_range_f64(const odouble4 *X, odouble4 *A_out, int i0, int i1, int j0, int j1, double eps2);
 
 /* One step of the OLDER snapshot (Sim-Without-OpenGL-Integration/kernel.cu:5-82): float3 velocity,
  * double-literal DT = 0.01 / EPS2 = 0.002, Jacobi order. V3 = N packed float3. */

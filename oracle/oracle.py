@@ -52,6 +52,7 @@ def lib() -> C.CDLL:
         L.oracle_step_jacobi.argtypes = [p, p, p, C.c_int, C.c_float, C.c_float]
         L.oracle_step_jacobi_f64acc.argtypes = [p, p, p, C.c_int, C.c_float, C.c_float]
         L.oracle_step_jacobi_f64.argtypes = [p, p, p, C.c_int, C.c_double, C.c_double]
+        L.oracle_accel_range_f64.argtypes = [p, p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]
         L.oracle_step_legacy.argtypes = [p, p, C.c_int]
         L.oracle_accel_range.argtypes = [p, p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
         L.oracle_integrate.argtypes = [p, p, p, C.c_int, C.c_float]
@@ -142,6 +143,15 @@ def accel_range(X, i0, i1, j0=0, j1=None, eps2=REF_EPS2, f64acc=False):
     j1 = len(X) if j1 is None else j1
     out = np.zeros((i1 - i0, 4), np.float32)
     lib().oracle_accel_range(_ptr(X), _ptr(out), i0, i1, j0, j1, float(eps2), 1 if f64acc else 0)
+    return out
+
+
+def accel_range_f64(X, i0, i1, j0=0, j1=None, eps2=REF_EPS2):
+    """All-double accelerations of targets [i0,i1) from sources [j0,j1); returns (i1-i0,4) float64."""
+    _chk(X, np.float64)
+    j1 = len(X) if j1 is None else j1
+    out = np.zeros((i1 - i0, 4), np.float64)
+    lib().oracle_accel_range_f64(_ptr(X), _ptr(out), i0, i1, j0, j1, float(eps2))
     return out
 
 

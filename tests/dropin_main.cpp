@@ -6,6 +6,7 @@
 #include <iostream>
 
 struct float4 { float x, y, z, w; };   // what <cuda_runtime.h> / <hip/hip_runtime.h> would provide
+struct float3 { float x, y, z; };
 
 #include "constants.h"
 #include "kernel.cuh"
@@ -51,6 +52,21 @@ int main(int argc, char** argv)
     nbody_memcpy_h2d(d_bodies, bodies, size4);
 
     if (simulationLoopNoVisual(d_bodies, d_accelerations, d_velocity, steps) != 0) return EXIT_FAILURE;
+
+    // every other declaration of utils.h / validation.h (utils.h:3-10, validation.h:6-8), once each
+    print_device_prop();
+    float3 v3[4], w3[4];
+    fill_with_zeroes3(v3, 4);
+    fill_with_zeroes3(w3, 4);
+    w3[2].y = random_float(5.0f, 6.0f);
+    const int off3 = verify_equality3(v3, w3, 4);
+    float4 copy[4];
+    copy_vector_bodies(bodies, copy, 4);
+    printf("helpers: off3=%d copy_ok=%d body1=", off3, (int)(copy[3].w == bodies[3].w && copy[0].x == bodies[0].x));
+    print_float4(bodies[1]);
+    printf(" v3=");
+    print_float3(w3[0]);
+    printf("\n");
 
     nbody_memcpy_d2h(check, d_bodies, size4);
     const int moved = verify_equality4(check, bodies, N_BODIES);   // bodies that moved by more than 0.01

@@ -8,6 +8,11 @@ Every file holds inputs and expected outputs only (data, no reference source):
   ref_cpu_n1024.npz     x0 = the reference's fill_with_random4 after srand(1) (utils.cpp:30-37, glibc
                         rand()), v0 = a0 = 0; x/v/a after K in {1,10,100} calls of the REFERENCE's
                         CPU_compute (validation.cpp:28-52; DT=0.1f, EPS2=0.002f compiled in).
+  ref_cpu_n8192.npz     the reference's SHIPPED configuration (constants.h:13,25-26: N_BODIES 8192, DT 0.1f,
+                        EPS2 0.002f, unseeded fill_with_random4): x/a after K = 1 and x/v/a after K = 10
+                        calls of the reference's CPU_compute. x0 itself is not stored (128 KiB): it is
+                        fill_with_random4 after srand(1), which the product's generator reproduces bit
+                        for bit; x0_head holds its first 8 bodies as a check.
   ref_pairs.npz         256 random (bi,bj,ai) triples and the reference's bodyInteractions_CPU result.
   jacobi_*.npz          outputs of OUR oracle's Jacobi step (fp32 sequential) for seeded inputs, so
                         the GPU box can check the strict kernel bit-for-bit without re-running the
@@ -43,6 +48,18 @@ def main():
         done = K
         out[f"x_{K}"], out[f"v_{K}"], out[f"a_{K}"] = x.copy(), v.copy(), a.copy()
     np.savez_compressed(os.path.join(OUT, "ref_cpu_n1024.npz"), **out)
+
+    # --- the reference's own shipped size ------------------------------------------------------
+    n = 8192
+    libc.srand(1)
+    x0 = O.ref_fill_with_random4(n)
+    x, v, a = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
+    out = {"x0_head": x0[:8].copy()}
+    O.ref_step(x, a, v, steps=1)
+    out["x_1"], out["a_1"] = x.copy(), a.copy()
+    O.ref_step(x, a, v, steps=9)
+    out["x_10"], out["v_10"], out["a_10"] = x.copy(), v.copy(), a.copy()
+    np.savez_compressed(os.path.join(OUT, "ref_cpu_n8192.npz"), **out)
 
     rng = np.random.default_rng(2024)
     bi = (rng.uniform(-1e5, 1e5, (256, 4))).astype(np.float32)

@@ -134,3 +134,18 @@ def test_launch_plan_is_always_buildable_and_covers_every_source(nb):
     assert _plan(nb, 5000, 5000, kernel=1, tile=256, bpl=4, jsplit=8)[:3] == (1, 1024, 1)
     # the sizes the docs quote
     assert _plan(nb, 262144, 262144)[:2] == (4, 2048) and _plan(nb, 8192, 8192)[:2] == (1, 256)
+
+
+def test_bench_defaults_name_the_baseline_configs():
+    """--gpus 1 runs configs[2] (N=262144); a dry look at what --gpus 8 would run: configs[3], N=1048576, strong."""
+    import importlib.util
+    root = ROOT
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.N_SINGLE == 262144 and b.N_MULTI == 1048576
+    assert b.default_workload(1, 0, "strong") == (262144, "weak")
+    for g in (2, 4, 8):
+        assert b.default_workload(g, 0, "strong") == (1048576, "strong")
+    assert b.default_workload(8, 0, "weak") == (720896, "weak")
+    assert b.default_workload(4, 65536, "strong") == (65536, "strong")

@@ -101,6 +101,9 @@ def test_source_level_dropin_with_reference_header_names(nb, tmp_path):
     assert r.returncode == 0, r.stderr
     out = _run([exe, "4"])
     assert "Starting the simulation..." in out and "Simulation complete" in out
+    # the rest of utils.h / validation.h, called once each by the same translation unit
+    assert "== Device Properties ==" in out and "Warp size: 64" in out
+    assert "verify_equality3: 1 of 4 bodies differ" in out and "helpers: off3=1 copy_ok=1 body1=" in out
     last = out.strip().splitlines()[-1]
     assert "N_BODIES=8192" in last and "DT=0.1" in last
     import ctypes

@@ -232,6 +232,59 @@ def test_reference_one_percent_rule_vs_literal_reference(nb):
     assert bad <= 64, bad   # ~3 % of 1024; caused by close encounters amplifying the ordering difference
 
 
+# ---- the reference's shipped configuration: N_BODIES 8192, DT 0.1f, unseeded init ----
+
+def _ref_n8192_start(nb):
+    import ctypes
+    ctypes.CDLL(None).srand(1)                       # an unseeded process starts in this state
+    return nb.engine.libc_random_bodies(8192)
+
+
+def test_reference_shipped_size_strict_bitwise(nb, oracle):
+    """constants.h:13,25-26 through the strict kernel: bit-identical to the Jacobi oracle after 1 and 3 steps."""
+    x0 = _ref_n8192_start(nb)
+    assert np.array_equal(bits(x0[:8]), bits(load_golden("ref_cpu_n8192.npz")["x0_head"]))
+    xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
+    for K, more in ((1, 1), (3, 2)):
+        oracle.step_jacobi(xo, ao, vo, dt=0.1, eps2=0.002, steps=more)
+        x, v, a = _gpu_run(nb, x0, K, 0.1, 0.002, nb.KERNEL_STRICT)
+        assert same_bits(x, xo) and same_bits(v, vo) and same_bits(a, ao), K
+
+
+@pytest.mark.parametrize("kernel", ["fast", "onesided", "symmetric"])
+def test_reference_shipped_size_fast_vs_literal_reference(nb, oracle, kernel):
+    """The fast kernels at the reference's own size. Against the Jacobi oracle (same arithmetic, race-free
+    order): positions to 1e-6 of the scale after 1 step, 1e-5 after 10, and the reference's 1 % rule passes
+    for every body. Against the LITERAL reference outputs (golden from the reference build; its CPU loop
+    advances body i before body i+1 reads it): at this size that in-place ordering alone moves two bodies by
+    0.1-0.4 position units in the first step and puts 11 of 8192 bodies outside its own 1 % rule after ten
+    (oracle vs oracle, computed here) — the GPU is within that ordering effect plus 1e-6 of the scale, and
+    fails the rule for no more bodies than the Jacobi oracle does (+2)."""
+    g = load_golden("ref_cpu_n8192.npz")
+    x0 = _ref_n8192_start(nb)
+    k = {"fast": nb.KERNEL_FAST, "onesided": nb.KERNEL_ONESIDED, "symmetric": nb.KERNEL_SYMMETRIC}[kernel]
+    sim = nb.engine.Simulation(x0, dt=0.1, eps2=0.002, kernel=k)
+    assert sim.ctx.step_info(8192)["symmetric"] == (kernel == "symmetric")
+    xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
+    oracle.step_jacobi(xo, ao, vo, dt=0.1, eps2=0.002, steps=1)
+    sim.run(1)
+    x, v, a = sim.state()
+    assert np.abs(x - xo)[:, :3].max() / 1e5 <= 1e-6
+    assert np.abs(a - ao)[:, :3].max() / np.abs(ao[:, :3]).max() <= 1e-5
+    ordering_x = np.abs(xo - g["x_1"])[:, :3]                      # in-place vs Jacobi, per component
+    assert np.all(np.abs(x - g["x_1"])[:, :3] <= ordering_x + 1e-6 * 1e5)
+    assert nb.engine.verify_still_bodies(x, g["x_1"]) == 0         # the reference's own acceptance rule
+    amax = np.abs(g["a_1"][:, :3]).max()
+    ordering_a = np.abs(ao - g["a_1"])[:, :3]
+    assert np.all(np.abs(a - g["a_1"])[:, :3] <= ordering_a + 1e-5 * amax)
+    oracle.step_jacobi(xo, ao, vo, dt=0.1, eps2=0.002, steps=9)
+    sim.run(9)
+    x10, _, _ = sim.state()
+    assert np.abs(x10 - xo)[:, :3].max() / 1e5 <= 1e-5
+    assert nb.engine.verify_still_bodies(x10, xo) == 0
+    assert nb.engine.verify_still_bodies(x10, g["x_10"]) <= nb.engine.verify_still_bodies(xo, g["x_10"]) + 2
+
+
 # ---- the drop-in boundary ---------------------------------------------------------------------------
 
 def test_simulate_dropin(nb, oracle):
@@ -401,6 +454,32 @@ def test_f64_step_matches_oracle(nb, oracle):
     # and the fp32 fast path agrees with fp64 to fp32 accuracy (BASELINE configs[4]'s tolerance check)
     xf, _, af = _gpu_run(nb, x0.astype(np.float32), 3, 0.01, 0.002, nb.KERNEL_FAST)
     assert np.abs(xf - xo)[:, :3].max() <= 2e-6
+
+
+def test_config5_f64_at_n262144(nb, oracle):
+    """configs[4] at its stated size: N=262144 fp64 on one GPU. Sampled targets against the checker's all-double
+    sum over all sources (1e-12 of max|a|), momentum balance in double, and the tolerance check against the fp32
+    engine from the same start after 4 steps (2e-6 of the Plummer scale radius). The fp64 kernel is the build's
+    own: it has no reference counterpart, so this parity is against the checker only ("parity unpinned")."""
+    n = 262144
+    x0 = nb.engine.seeded_bodies(n, 1, 12345)
+    x64 = x0.astype(np.float64)
+    ctx = nb.engine.Context()
+    x = torch.from_numpy(x64).cuda()
+    v = torch.zeros_like(x)
+    a = torch.zeros_like(x)
+    ctx.step_f64(x, a, v, dt=0.01, eps2=0.002, steps=1)
+    ctx.sync()
+    ag = a.cpu().numpy()
+    for i0 in (0, 131000):
+        want = oracle.accel_range_f64(x64, i0, i0 + 256, 0, n, eps2=0.002)
+        assert np.abs(ag[i0:i0 + 256] - want)[:, :3].max() / np.abs(want[:, :3]).max() <= 1e-12
+    m = x64[:, 3:4]
+    assert np.abs((m * ag[:, :3]).sum(0)).max() / (m * np.abs(ag[:, :3])).sum() < 1e-13
+    ctx.step_f64(x, a, v, dt=0.01, eps2=0.002, steps=3)
+    ctx.sync()
+    xf, _, _ = _gpu_run(nb, x0, 4, 0.01, 0.002, nb.KERNEL_FAST)
+    assert np.abs(xf - x.cpu().numpy())[:, :3].max() <= 2e-6
 
 
 # ---- hipGraph replay of launch-bound steps ---------------------------------------------------------------

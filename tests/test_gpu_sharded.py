@@ -140,3 +140,31 @@ def test_sharded_hip_backend_multi_rank_over_gloo(nb, oracle, world, n):
         assert np.abs(x - xo)[:, :3].max() <= 1e-6
         assert np.abs(a - ao)[:, :3].max() / np.abs(ao[:, :3]).max() <= 1e-5
         assert np.array_equal(x, res[0][1])
+
+
+def _run_bench(args, timeout=600):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None), env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable] + args, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 prints ONE JSON line, the other ranks nothing
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_over_gloo_on_one_gpu():
+    """bench.py exactly as the driver launches it for N > 1 (python -m torch.distributed.run, one process per
+    rank; the launcher starts before anything touches the GPU), rehearsed with 2 ranks sharing this box's one
+    GPU over gloo: one JSON line, n_gpus 2, strong scaling, the per-step communication report present."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    line = _run_bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                       "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                       "--bodies", "65536", "--steps", "3", "--warmup", "1", "--repeats", "2"])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["repeats"] == 2
+    assert line["scaling"] == "strong" and line["config"]["n_bodies"] == 65536
+    assert line["config"]["comm_rank0"]["steps"] >= 3
+    assert line["value"] > 1e11 and 0 < line["roofline"]["frac"] < 1

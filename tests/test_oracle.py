@@ -31,6 +31,23 @@ def test_inplace_oracle_matches_golden_reference_outputs(oracle):
         assert np.array_equal(bits(a), bits(g[f"a_{K}"])), f"accelerations differ after {K} steps"
 
 
+def test_inplace_oracle_matches_reference_at_its_shipped_size(oracle, nb):
+    """The reference's own configuration (constants.h:13,25-26: N_BODIES 8192, DT 0.1f, EPS2 0.002f, unseeded
+    fill_with_random4): the restatement of validation.cpp:28-52 reproduces the reference build's outputs
+    (tests/golden/ref_cpu_n8192.npz) bit for bit after 1 and 10 steps, starting from the product's generator."""
+    import ctypes
+    g = load_golden("ref_cpu_n8192.npz")
+    ctypes.CDLL(None).srand(1)
+    x0 = nb.engine.libc_random_bodies(8192)
+    assert np.array_equal(bits(x0[:8]), bits(g["x0_head"]))
+    x, v, a = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
+    oracle.step_inplace(x, a, v, steps=1)
+    assert np.array_equal(bits(x), bits(g["x_1"])) and np.array_equal(bits(a), bits(g["a_1"]))
+    oracle.step_inplace(x, a, v, steps=9)
+    assert np.array_equal(bits(x), bits(g["x_10"])) and np.array_equal(bits(v), bits(g["v_10"]))
+    assert np.array_equal(bits(a), bits(g["a_10"]))
+
+
 def test_pair_matches_golden_reference_pairs(oracle):
     g = load_golden("ref_pairs.npz")
     for k in range(len(g["bi"])):
