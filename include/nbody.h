@@ -156,6 +156,16 @@ int nbody_accel_range(nbody_ctx* ctx, const nbody_float4* d_bodies, nbody_float4
 int nbody_accel_wrapped(nbody_ctx* ctx, const nbody_float4* d_bodies, int n_total,
                         nbody_float4* d_acc_out, int i0, int i1, int j0, int count, int accumulate);
 
+/* SYMMETRIC evaluation of two DISJOINT sets of bodies of one array of n_total: targets [i0,i1) against the
+ * source run j0, j0+1, ..., j0+count-1 (indices modulo n_total; the run must not touch [i0,i1)). Every pair
+ * (i, j) is evaluated once and applied to both bodies (Newton's third law): d_acc_i[i1-i0] receives (or, with
+ * accumulate_i != 0, continues) the accelerations the sources exert on the targets, d_acc_j_out[count] is
+ * OVERWRITTEN with the accelerations the targets exert on the sources, in run order. FAST arithmetic only.
+ * This is what a rank of the sharded step calls for the blocks of other ranks it is responsible for: the
+ * second output is what it sends back to their owners. Asynchronous. */
+int nbody_accel_cross(nbody_ctx* ctx, const nbody_float4* d_bodies, int n_total, nbody_float4* d_acc_i, int i0,
+                      int i1, int accumulate_i, int j0, int count, nbody_float4* d_acc_j_out);
+
 /* Integrate bodies [i0,i1): d_bodies is the whole array (indexed absolutely), d_velocity and
  * d_acc hold the i1-i0 own entries. Asynchronous. */
 int nbody_integrate_range(nbody_ctx* ctx, nbody_float4* d_bodies, nbody_float4* d_velocity,

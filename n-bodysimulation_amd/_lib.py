@@ -53,6 +53,7 @@ _SIGNATURES = {
     "nbody_step": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int]),
     "nbody_accel_range": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "nbody_accel_wrapped": (C.c_int, [_p, _p, C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "nbody_accel_cross": (C.c_int, [_p, _p, C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "nbody_integrate_range": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int]),
     "nbody_ctx_sync": (C.c_int, [_p]),
     "nbody_ctx_timing": (C.c_int, [_p, C.c_int]),

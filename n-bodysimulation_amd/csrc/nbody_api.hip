@@ -219,6 +219,47 @@ bool sym_resolve(const nbody_ctx* c, int n, SymShape* out)
     return true;
 }
 
+// one range of n bodies starting at absolute index i0 against itself
+void sym_square_params(nbk::SymParams* sp, const float4* x, int i0, int n, const SymShape& y, float4* slabs, float eps2)
+{
+    *sp = nbk::SymParams{};
+    sp->x = x;
+    sp->slabs_i = slabs;
+    sp->slabs_j = slabs;
+    sp->ni = n; sp->nj = n;
+    sp->i0 = i0; sp->j0 = i0;
+    sp->wrap = 0;
+    sp->nbi = y.nb; sp->nbj = y.nb;
+    sp->stride_i = n; sp->stride_j = n;
+    sp->rect = 0;
+    sp->eps2 = eps2;
+}
+
+// Block shape for the symmetric evaluation of TWO disjoint ranges (ni x nj bodies): the largest block that
+// still gives about eight workgroups per CU.
+bool sym_resolve_cross(const nbody_ctx* c, int ni, int nj, SymShape* out, int* nbj)
+{
+    int pick = -1;
+    for (int k = 0; k < kSymCands; ++k) {
+        if ((c->sym_waves && kSymCand[k][0] != c->sym_waves) || (c->sym_bpl && kSymCand[k][1] != c->sym_bpl)) continue;
+        pick = k;
+        const long B = 64L * kSymCand[k][0] * kSymCand[k][1];
+        if (((ni + B - 1) / B) * ((nj + B - 1) / B) >= 8L * c->num_cu) break;
+    }
+    if (pick < 0) return false;
+    SymShape y{};
+    y.waves = kSymCand[pick][0];
+    y.bpl = kSymCand[pick][1];
+    y.block = 64 * y.waves * y.bpl;
+    y.nb = (ni + y.block - 1) / y.block;
+    const int bj = (nj + y.block - 1) / y.block;
+    y.grid = y.nb * bj;
+    if (y.nb > kSymMaxSlabs || bj > 4 * kSymMaxSlabs) return false;
+    *out = y;
+    *nbj = bj;
+    return true;
+}
+
 // Does a square problem of n bodies (targets == sources) go to the symmetric kernel?
 bool sym_wanted(const nbody_ctx* c, int n, SymShape* out)
 {
@@ -561,12 +602,7 @@ int accel_impl(nbody_ctx* c, const nbody_float4* d_bodies, nbody_float4* d_acc_o
         // a square block (targets == sources): every unordered pair once
         if (int rc = ensure_slabs(c, (size_t)y.nb * nt * sizeof(float4))) return rc;
         nbk::SymParams sp{};
-        sp.x = reinterpret_cast<const float4*>(d_bodies) + i0;
-        sp.slabs = static_cast<float4*>(c->slabs);
-        sp.n = nt;
-        sp.nb = y.nb;
-        sp.stride = nt;
-        sp.eps2 = c->eps2;
+        sym_square_params(&sp, reinterpret_cast<const float4*>(d_bodies), i0, nt, y, static_cast<float4*>(c->slabs), c->eps2);
         if (int rc = launch_sym(c, y, sp)) return rc;
         nbk::ReduceParams r{};
         r.out = reinterpret_cast<float4*>(d_acc_out);
@@ -635,6 +671,66 @@ int nbody_accel_wrapped(nbody_ctx* c, const nbody_float4* d_bodies, int n_total,
     return accel_impl(c, d_bodies, d_acc_out, i0, i1, j0, j0 + count, n_total, accumulate);
 }
 
+int nbody_accel_cross(nbody_ctx* c, const nbody_float4* d_bodies, int n_total, nbody_float4* d_acc_i, int i0, int i1,
+                      int accumulate_i, int j0, int count, nbody_float4* d_acc_j_out)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (n_total <= 0 || i0 < 0 || i1 < i0 || i1 > n_total || j0 < 0 || j0 >= n_total || count < 0 || count > n_total - (i1 - i0))
+        return fail(NBODY_ERR_INVALID, "bad cross range: n=%d i[%d,%d) j0=%d count=%d", n_total, i0, i1, j0, count);
+    // the source run j0 .. j0+count-1 (mod n_total) must not meet the targets: a shared body would be paired with itself
+    {
+        const long a0 = j0, a1 = (long)j0 + count;          // [a0,a1) possibly beyond n_total
+        const bool hit = (i0 < a1 && a0 < i1) || (a1 > n_total && i0 < a1 - n_total);
+        if (hit && count > 0 && i1 > i0) return fail(NBODY_ERR_INVALID, "cross ranges overlap: i[%d,%d) j0=%d count=%d (n=%d)", i0, i1, j0, count, n_total);
+    }
+    if (c->kernel == NBODY_KERNEL_STRICT)
+        return fail(NBODY_ERR_CONFIG, "nbody_accel_cross is a FAST-arithmetic entry: the strict kernel keeps one sequential sum per target");
+    const int ni = i1 - i0;
+    if (ni == 0) return NBODY_OK;
+    if (!d_bodies || !d_acc_i || (count > 0 && !d_acc_j_out)) return fail(NBODY_ERR_INVALID, "null device pointer");
+    ON_DEVICE(c);
+    if (count == 0) {
+        if (!accumulate_i) HIP_TRY(hipMemsetAsync(d_acc_i, 0, (size_t)ni * sizeof(float4), c->stream));
+        return NBODY_OK;
+    }
+    SymShape y{};
+    int nbj = 0;
+    if (!sym_resolve_cross(c, ni, count, &y, &nbj)) return fail(NBODY_ERR_CONFIG, "no symmetric kernel shape for %d x %d bodies", ni, count);
+    // workspace: nbj I-side slabs of ni bodies, then nbi J-side slabs of `count` bodies
+    const size_t islabs = (size_t)nbj * ni, jslabs = (size_t)y.nb * count;
+    if (int rc = ensure_slabs(c, (islabs + jslabs) * sizeof(float4))) return rc;
+    nbk::SymParams sp{};
+    sp.x = reinterpret_cast<const float4*>(d_bodies);
+    sp.slabs_i = static_cast<float4*>(c->slabs);
+    sp.slabs_j = static_cast<float4*>(c->slabs) + islabs;
+    sp.ni = ni; sp.nj = count;
+    sp.i0 = i0; sp.j0 = j0;
+    sp.wrap = n_total;
+    sp.nbi = y.nb; sp.nbj = nbj;
+    sp.stride_i = ni; sp.stride_j = count;
+    sp.rect = 1;
+    sp.eps2 = c->eps2;
+    if (int rc = launch_sym(c, y, sp)) return rc;
+    nbk::ReduceParams r{};
+    r.out = reinterpret_cast<float4*>(d_acc_i);
+    r.slabs = sp.slabs_i;
+    r.nslab = nbj;
+    r.slab_stride = ni;
+    r.n = ni;
+    r.accumulate = accumulate_i ? 1 : 0;
+    nbk::reduce_slabs<<<(ni + nbk::kWG - 1) / nbk::kWG, nbk::kWG, 0, c->stream>>>(r);
+    HIP_TRY(hipGetLastError());
+    r.out = reinterpret_cast<float4*>(d_acc_j_out);
+    r.slabs = sp.slabs_j;
+    r.nslab = y.nb;
+    r.slab_stride = count;
+    r.n = count;
+    r.accumulate = 0;
+    nbk::reduce_slabs<<<(count + nbk::kWG - 1) / nbk::kWG, nbk::kWG, 0, c->stream>>>(r);
+    HIP_TRY(hipGetLastError());
+    return NBODY_OK;
+}
+
 int nbody_integrate_range(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_velocity, const nbody_float4* d_acc,
                           int i0, int i1)
 {
@@ -679,12 +775,7 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
     q.dt = c->dt;
     if (sym) {
         if (int rc = ensure_slabs(c, (size_t)y.nb * n * sizeof(float4))) return rc;
-        sp.x = reinterpret_cast<const float4*>(d_bodies);
-        sp.slabs = static_cast<float4*>(c->slabs);
-        sp.n = n;
-        sp.nb = y.nb;
-        sp.stride = n;
-        sp.eps2 = c->eps2;
+        sym_square_params(&sp, reinterpret_cast<const float4*>(d_bodies), 0, n, y, static_cast<float4*>(c->slabs), c->eps2);
         q.slabs = static_cast<const float4*>(c->slabs);
         q.nslab = y.nb;
         q.slab_stride = n;

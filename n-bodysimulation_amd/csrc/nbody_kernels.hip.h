@@ -302,11 +302,17 @@ __global__ void __launch_bounds__(kWG, MINW) force_sgpr(const ForceParams p)
 // index order: deterministic, no float atomics.
 
 struct SymParams {
-    const float4* x;   // bodies {x,y,z,mass}
-    float4* slabs;     // nb slabs, `stride` float4 apart
-    int n;             // bodies
-    int nb;            // blocks: ceil(n / B)
-    int stride;
+    const float4* x;      // bodies {x,y,z,mass}, indexed absolutely
+    float4* slabs_i;      // I-side partial sums: slab s at slabs_i + s*stride_i, element = index within the I range
+    float4* slabs_j;      // J-side partial sums: slab s at slabs_j + s*stride_j, element = index within the J run
+    int ni, nj;           // bodies of the I range / of the J run
+    int i0, j0;           // absolute index of the first I / first J body
+    int wrap;             // 0, or the array length: a J index at or beyond it continues at body 0
+    int nbi, nbj;         // blocks of B bodies on each side
+    int stride_i, stride_j;
+    int rect;             // 0: ONE range (I range == J run): block pairs I < J once + the diagonal blocks one-sided
+                          //    (nbi == nbj == nb, slabs_i == slabs_j: slab J gets the I-side sums, slab I the J-side sums)
+                          // 1: TWO disjoint ranges: every (I, J) block pair, symmetric; slab J of slabs_i, slab I of slabs_j
     float eps2;
 };
 
@@ -474,7 +480,8 @@ __device__ __forceinline__ float next_row(const float v, const int addr)
 // first index of row I in the row-major list of block pairs (I < J): I*(2nb - I - 1)/2
 __device__ __forceinline__ int sym_row_offset(int I, int nb) { return (int)(((long)I * (2L * nb - I - 1)) / 2); }
 
-// grid = nb*(nb-1)/2 pair tasks followed by nb diagonal tasks; block = 64*W threads.
+// block = 64*W threads. rect == 0: grid = nb*(nb-1)/2 pair tasks followed by nb diagonal tasks;
+// rect == 1: grid = nbi*nbj pair tasks.
 template <class M, int W, int MINW = 1>
 __global__ void __launch_bounds__(64 * W, MINW) force_sym(const SymParams p)
 {
@@ -486,36 +493,46 @@ __global__ void __launch_bounds__(64 * W, MINW) force_sym(const SymParams p)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int npair = p.nb * (p.nb - 1) / 2;
     int I, J;
+    bool diag = false;
     const int task = blockIdx.x;
-    const bool diag = task >= npair;
-    if (diag) {
-        I = J = task - npair;
+    if (p.rect) {
+        I = task % p.nbi;
+        J = task / p.nbi;
     } else {
-        const float q = 2.0f * p.nb - 1.0f;
-        I = (int)((q - __builtin_sqrtf(q * q - 8.0f * (float)task)) * 0.5f);
-        if (I < 0) I = 0;
-        if (I > p.nb - 2) I = p.nb - 2;
-        while (I < p.nb - 2 && sym_row_offset(I + 1, p.nb) <= task) ++I;
-        while (I > 0 && sym_row_offset(I, p.nb) > task) --I;
-        J = I + 1 + (task - sym_row_offset(I, p.nb));
+        const int npair = p.nbi * (p.nbi - 1) / 2;
+        diag = task >= npair;
+        if (diag) {
+            I = J = task - npair;
+        } else {
+            const float q = 2.0f * p.nbi - 1.0f;
+            I = (int)((q - __builtin_sqrtf(q * q - 8.0f * (float)task)) * 0.5f);
+            if (I < 0) I = 0;
+            if (I > p.nbi - 2) I = p.nbi - 2;
+            while (I < p.nbi - 2 && sym_row_offset(I + 1, p.nbi) <= task) ++I;
+            while (I > 0 && sym_row_offset(I, p.nbi) > task) --I;
+            J = I + 1 + (task - sym_row_offset(I, p.nbi));
+        }
     }
 
+    // a body past the end of its range is replaced by a massless one at the origin: it adds exactly
+    // +-0 to every real body, and what it collects itself is never stored
     M t;
     t.set_eps2(p.eps2);
-    const int ibase = I * B + w * (64 * BPL) + lane;
+    const int ibase = I * B + w * (64 * BPL) + lane;  // index within the I range
 #pragma unroll
     for (int k = 0; k < BPL; ++k) {
         const int i = ibase + k * 64;
-        t.set(k, i < p.n ? p.x[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        t.set(k, i < p.ni ? p.x[p.i0 + i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     }
-    const int jbase = J * B + lane;
+    const int jbase = J * B + lane;  // index within the J run
     const int rot = ((lane + 16) & 63) << 2;
 
     auto fetch = [&](int c) {
         const int j = jbase + c * 64;
-        return j < p.n ? p.x[j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        int ja = p.j0 + j;
+        if (p.wrap && ja >= p.wrap) ja -= p.wrap;
+        return j < p.nj ? p.x[ja] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     };
 
     if (!diag) {
@@ -548,17 +565,17 @@ __global__ void __launch_bounds__(64 * W, MINW) force_sym(const SymParams p)
         c = cn;
     }
 
-    float4* const out_i = p.slabs + (size_t)J * p.stride;
+    float4* const out_i = p.slabs_i + (size_t)J * p.stride_i;
 #pragma unroll
     for (int k = 0; k < BPL; ++k) {
         const int i = ibase + k * 64;
-        if (i < p.n) out_i[i] = t.acc(k);
+        if (i < p.ni) out_i[i] = t.acc(k);
     }
     if (!diag) {
-        float4* const out_j = p.slabs + (size_t)I * p.stride;
+        float4* const out_j = p.slabs_j + (size_t)I * p.stride_j;
         for (int e = tid; e < B; e += 64 * W) {
             const int j = J * B + e;
-            if (j < p.n) {
+            if (j < p.nj) {
                 float4 a = sh[e];
                 a.w = 0.0f;
                 out_j[j] = a;

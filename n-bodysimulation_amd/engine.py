@@ -139,6 +139,14 @@ class Context:
         check(self._lib.nbody_accel_wrapped(self._h, _dptr(x), x.shape[0], _dptr(a_out), i0, i1, j0, count,
                                             1 if accumulate else 0))
 
+    def accel_cross(self, x: torch.Tensor, a_i: torch.Tensor, i0: int, i1: int, accumulate_i: bool, j0: int, count: int,
+                    a_j_out: torch.Tensor) -> None:
+        """Symmetric evaluation of targets [i0,i1) x the source run j0..j0+count-1 (mod len(x)), disjoint sets:
+        a_i (+)= what the sources do to the targets, a_j_out = what the targets do to the sources."""
+        _check_f4(x), _check_f4(a_i, i1 - i0), _check_f4(a_j_out, count)
+        check(self._lib.nbody_accel_cross(self._h, _dptr(x), x.shape[0], _dptr(a_i), i0, i1, 1 if accumulate_i else 0,
+                                          j0, count, _dptr(a_j_out)))
+
     def integrate_range(self, x: torch.Tensor, v_own: torch.Tensor, a_own: torch.Tensor, i0: int, i1: int) -> None:
         _check_f4(x), _check_f4(v_own, i1 - i0), _check_f4(a_own, i1 - i0)
         if i1 > x.shape[0]:

@@ -199,6 +199,60 @@ def test_symmetric_vs_onesided_at_n65536(nb, oracle):
     assert np.abs(out["fast"] - out["one"])[:, :3].max() / an <= 2e-5
 
 
+@pytest.mark.parametrize("waves,bpl", [(0, 0), (1, 2), (2, 8)])
+@pytest.mark.parametrize("n,i0,i1,j0,count", [(3000, 1000, 1750, 1750, 1100),   # plain run after the targets
+                                              (3000, 2250, 3000, 0, 900),        # run starts at 0
+                                              (3000, 1000, 1750, 2500, 1300),    # run wraps past the end
+                                              (5000, 100, 133, 4000, 1050),      # few targets, wrapping run
+                                              (4096, 0, 2048, 2048, 2048)])      # whole blocks
+def test_accel_cross_two_disjoint_sets(nb, oracle, waves, bpl, n, i0, i1, j0, count):
+    """nbody_accel_cross: every (target, source) pair once, both sides' accelerations. Targets' sums and sources'
+    sums against the fp64-accumulated CPU sums over exactly those pairs; sum of m*a over both sets is zero."""
+    x0 = nb.engine.seeded_bodies(n, 0, 77)
+    ctx = nb.engine.Context()
+    ctx.set_symmetric_shape(waves, bpl)
+    x = torch.from_numpy(x0).cuda()
+    ai = torch.full((i1 - i0, 4), 5.0, device="cuda")
+    aj = torch.full((count, 4), 9.0, device="cuda")
+    ctx.accel_cross(x, ai, i0, i1, False, j0, count, aj)
+    ctx.sync()
+    run = (np.arange(count) + j0) % n
+    # reorder so that the run is contiguous: targets first, then the run
+    xs = np.ascontiguousarray(np.concatenate([x0[i0:i1], x0[run]]))
+    ni = i1 - i0
+    want_i = oracle.accel_range(xs, 0, ni, ni, ni + count, eps2=0.002, f64acc=True)
+    want_j = oracle.accel_range(xs, ni, ni + count, 0, ni, eps2=0.002, f64acc=True)
+    gi, gj = ai.cpu().numpy(), aj.cpu().numpy()
+    assert np.abs(gi - want_i)[:, :3].max() / np.abs(want_i[:, :3]).max() <= 1e-5
+    assert np.abs(gj - want_j)[:, :3].max() / np.abs(want_j[:, :3]).max() <= 1e-5
+    assert np.all(gi[:, 3] == 0) and np.all(gj[:, 3] == 0)
+    mi, mj = xs[:ni, 3:4].astype(np.float64), xs[ni:, 3:4].astype(np.float64)
+    net = (mi * gi[:, :3]).sum(0) + (mj * gj[:, :3]).sum(0)
+    assert np.abs(net).max() / ((mi * np.abs(gi[:, :3])).sum() + (mj * np.abs(gj[:, :3])).sum()) < 1e-6
+    # accumulate_i continues the targets' sums; the sources' output is always overwritten
+    ctx.accel_cross(x, ai, i0, i1, True, j0, count, aj)
+    ctx.sync()
+    assert np.abs(ai.cpu().numpy() - 2 * gi)[:, :3].max() / np.abs(gi[:, :3]).max() <= 1e-6
+    assert np.array_equal(aj.cpu().numpy(), gj)
+
+
+def test_accel_cross_rejects_overlap_and_strict(nb):
+    x = torch.zeros((1000, 4), device="cuda")
+    a = torch.zeros((100, 4), device="cuda")
+    b = torch.zeros((300, 4), device="cuda")
+    ctx = nb.engine.Context()
+    with pytest.raises(nb.NBodyError):
+        ctx.accel_cross(x, a, 100, 200, False, 150, 300, b)      # run starts inside the targets
+    with pytest.raises(nb.NBodyError):
+        ctx.accel_cross(x, a, 100, 200, False, 900, 300, b)      # run wraps into the targets
+    ctx.accel_cross(x, a, 100, 200, False, 200, 300, b)          # adjacent is fine
+    ctx.accel_cross(x, a, 100, 200, False, 950, 150, b[:150])    # wraps to [0,100): touches nothing
+    strict = nb.engine.Context(kernel=nb.KERNEL_STRICT)
+    with pytest.raises(nb.NBodyError):
+        strict.accel_cross(x, a, 100, 200, False, 200, 300, b)
+    ctx.sync()
+
+
 def test_symmetric_shape_errors(nb):
     ctx = nb.engine.Context()
     with pytest.raises(nb.NBodyError):

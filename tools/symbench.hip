@@ -193,7 +193,8 @@ int main(int argc, char** argv)
         const int nb = (n + v.B - 1) / v.B;
         if (nb > max_slabs || nb < 2) continue;
         nbk::SymParams sp{};
-        sp.x = dx; sp.slabs = slabs; sp.n = n; sp.nb = nb; sp.stride = n; sp.eps2 = eps2;
+        sp.x = dx; sp.slabs_i = slabs; sp.slabs_j = slabs; sp.ni = n; sp.nj = n; sp.i0 = 0; sp.j0 = 0; sp.wrap = 0; sp.nbi = nb; sp.nbj = nb;
+        sp.stride_i = n; sp.stride_j = n; sp.rect = 0; sp.eps2 = eps2;
         const int grid = nb * (nb - 1) / 2 + nb;
         auto run = [&] {
             v.launch(sp, grid);
