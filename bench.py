@@ -212,7 +212,6 @@ def main():
     f64 = args.dtype == "f64"
     if f64 and world > 1:
         raise SystemExit("--dtype f64 is a single-GPU variant")
-    backend = None
     if f64:
         class _F64Sim:   # same alloc/init/H2D sequence as engine.Simulation, double state
             def __init__(self):
@@ -241,13 +240,20 @@ def main():
         sync = ctx.sync
         info = ctx.step_info(n)
     else:
-        backend = nbody_amd.sharded.HipBackend(dev, args.dt, args.eps2, **kopts)
-        sim = nbody_amd.sharded.ShardedSimulation(x0, dt=args.dt, eps2=args.eps2, backend=backend)
-        ctx = sim.backend.ctx
+        sim = nbody_amd.sharded.ShardedSimulation(x0, dt=args.dt, eps2=args.eps2, device=dev, sym_waves=args.sym_waves,
+                                                  sym_bpl=args.sym_bpl, **kopts)
+        ctx = sim.ctx
         run = sim.step
         sync = sim.sync
-        info = ctx.step_info(sim.shard)   # the own-block pass; the remote pass is one one-sided launch over the other blocks
-        info["evaluated_pairs"] += float(sim.shard) * (sim.n_pad - sim.shard)
+        info = ctx.step_info(sim.shard)   # the own-block pass
+        plan = sim.plan
+        if plan.schedule == nbody_amd.sharded.SCHEDULE_SYMMETRIC:   # + the cross launches: each pair once, both sides
+            cross = sum(float(plan.launch[l].i1 - plan.launch[l].i0) * plan.launch[l].count for l in range(plan.n_launches))
+        else:                                                       # + own targets x every other block, one-sided
+            cross = float(sim.shard) * (sim.n_pad - sim.shard)
+        info["evaluated_pairs"] += cross
+        info["schedule"] = {0: "canonical", 1: "onesided", 2: "symmetric"}[plan.schedule]
+        info["cross_launches"] = [[plan.launch[l].i0, plan.launch[l].i1, plan.launch[l].j0, plan.launch[l].count] for l in range(plan.n_launches)]
 
     red_dev = dev if args.backend == "nccl" else "cpu"
 
@@ -267,7 +273,7 @@ def main():
     run(args.warmup)
     barrier()
     if world > 1:
-        backend.comm_timing = True
+        sim.comm_timing(True)
     ctx.timing(True)
     repeats, kernel_ms, kernel_launches = [], [], 0
     target = args.repeats if args.repeats > 0 else 3
@@ -284,7 +290,7 @@ def main():
         if args.repeats <= 0 and len(repeats) == 1:
             target = min(max(3, int(math.ceil(3.0 / max(elapsed, 1e-6)))), 25)   # same on every rank: from the reduced time
     ctx.timing(False)
-    comm = backend.comm_report() if world > 1 else None
+    comm = sim.comm_report() if world > 1 else None
 
     elapsed = statistics.median(repeats)
     pairs_step = float(n) * n
@@ -342,7 +348,8 @@ def main():
                         f"dt={args.dt}, eps2={args.eps2}" + (f", {world} GPUs, {scaling} scaling" if world > 1 else ""),
             "n_bodies": n,
             "pairs_per_step": pairs_step,
-            "partition": "single GPU" if world == 1 else f"{world} contiguous blocks of {sim.shard} bodies, {args.backend} all-gather of positions per step",
+            "partition": "single GPU" if world == 1 else (f"{world} contiguous blocks of {sim.shard} bodies, {args.backend} all-gather of positions per step" +
+                                                                  (", every unordered pair once across the ranks, J-side sums exchanged (grouped send/recv)" if info.get("schedule") == "symmetric" else "")),
             "kernel": nbody_amd.load().nbody_version().decode(),
             "launch": info,
             "gflops_at_20_flop_per_pair": value * FLOP_PER_PAIR / 1e9,

@@ -173,6 +173,109 @@ int nbody_integrate_range(nbody_ctx* ctx, nbody_float4* d_bodies, nbody_float4* 
 
 int nbody_ctx_sync(nbody_ctx* ctx);
 
+/* The context's device, kernel id (NBODY_KERNEL_*) and launch stream (hipStream_t as void*). Any out pointer may be NULL. */
+int nbody_ctx_get(nbody_ctx* ctx, int* device, int* kernel, void** hip_stream);
+
+/* ---- sharded step: one rank per GPU (no reference analogue: the reference drives device 0 only, ------------
+ *      kernel.cu:630, main.cpp:287; this lifts that) ---------------------------------------------------------
+ *
+ * The bodies are cut into `world` contiguous blocks of `shard` bodies (n_total padded with massless bodies to
+ * world*shard, shard even). Rank r owns block r: its velocities and accelerations never leave the rank; every rank
+ * holds all positions. Per step, on rank r:
+ *
+ *   schedule SYMMETRIC (ctx kernel FAST or SYMMETRIC) — every unordered pair of bodies evaluated once in the machine:
+ *     comm stream     all-gather of positions (in place, shard*16 B per rank)        | overlapped with
+ *     compute stream  own block x own block, symmetric kernel                        | each other
+ *     compute stream  own block x the blocks r+1 .. r+(world-1)/2 (for an even world the block half-way round is
+ *                     shared between its two ranks): nbody_accel_cross — the J-side sums belong to OTHER ranks
+ *     comm stream     exchange: those J-side sums go to their owners, this rank's arrive (grouped send/recv)
+ *     compute stream  add the received sums in a fixed order, integrate the own block
+ *   schedule ONESIDED (ctx kernel ONESIDED): all-gather overlapped with own x own, then own x everybody else in ONE
+ *     one-sided launch over a source run that wraps around the end of the array; no exchange.
+ *   schedule CANONICAL (ctx kernel STRICT): all-gather, then own x [0, n) in index order — bit-identical to the
+ *     single-device strict step, no overlap (the parity path).
+ *
+ * Communication goes through two callbacks (nbody_comm), so the same executor runs over RCCL from C
+ * (nbody_comm_rccl_*), over torch.distributed from Python (n-bodysimulation_amd/sharded.py), or over plain device
+ * copies when one process drives several "ranks" on one GPU in a test. */
+
+enum { NBODY_SCHEDULE_CANONICAL = 0, NBODY_SCHEDULE_ONESIDED = 1, NBODY_SCHEDULE_SYMMETRIC = 2 };
+#define NBODY_MAX_RANKS 64
+
+typedef struct nbody_cross_launch {
+    int i0, i1;     /* targets: a sub-range of the own block (absolute indices) */
+    int j0, count;  /* source run j0, j0+1, ... (mod n_pad), `count` bodies of other ranks */
+    int jbuf_offset; /* where this launch's J-side sums start in the rank's J buffer (bodies) */
+} nbody_cross_launch;
+
+typedef struct nbody_shard_segment {
+    int peer;    /* the other rank */
+    int offset;  /* first body of the segment in this rank's J buffer (sends) / receive buffer (recvs) */
+    int count;   /* bodies */
+    int body0;   /* absolute index of the body the first entry belongs to */
+} nbody_shard_segment;
+
+typedef struct nbody_shard_plan_t {
+    int rank, world, n_total, schedule;
+    int shard, n_pad, i0, i1;       /* own block [i0,i1) = [rank*shard, (rank+1)*shard) */
+    int n_launches;                 /* symmetric schedule: 0..2 nbody_accel_cross launches */
+    nbody_cross_launch launch[2];
+    int jbuf_bodies;                /* J buffer: the launches' J-side sums back to back */
+    int n_sends, n_recvs;
+    nbody_shard_segment send[NBODY_MAX_RANKS];
+    nbody_shard_segment recv[NBODY_MAX_RANKS]; /* in the order the received sums are added */
+    int rbuf_bodies;                /* receive buffer */
+} nbody_shard_plan_t;
+
+/* Pure host logic (no device, no context): what rank `rank` of `world` does for n_total bodies under `schedule`. */
+int nbody_shard_plan(int rank, int world, int n_total, int schedule, nbody_shard_plan_t* out);
+
+/* The two collective operations of the step. Both ENQUEUE on hip_stream (a hipStream_t) and return 0, or non-zero
+ * on failure; neither may block the host on the GPU. */
+typedef struct nbody_comm {
+    void* user;
+    /* in-place all-gather over the ranks: rank r contributes the `bodies_per_rank` bodies at d_x_full + r*bodies_per_rank */
+    int (*all_gather)(void* user, nbody_float4* d_x_full, int bodies_per_rank, void* hip_stream);
+    /* one grouped exchange: send[k] = `count` bodies at d_jbuf + offset to `peer`; recv[k] = `count` bodies from `peer`
+     * into d_rbuf + offset. Every rank calls it once per step, also with nothing to send or receive. */
+    int (*exchange)(void* user, const nbody_shard_segment* send, int n_sends, const nbody_float4* d_jbuf,
+                    const nbody_shard_segment* recv, int n_recvs, nbody_float4* d_rbuf, void* hip_stream);
+} nbody_comm;
+
+/* RCCL over xGMI from C, without a link-time dependency: librccl.so is loaded on first use. Rank 0 makes a unique
+ * id (128 bytes), the caller distributes it to every rank by its own means, every rank creates its communicator. */
+int nbody_comm_rccl_unique_id(void* out_128_bytes);
+int nbody_comm_rccl_create(nbody_comm* out, int rank, int world, const void* unique_id_128_bytes);
+int nbody_comm_rccl_destroy(nbody_comm* comm);
+
+typedef struct nbody_shard nbody_shard;
+
+/* A rank of the sharded step. Owns the rank's device state on ctx's device: all positions (n_pad bodies), the own
+ * block's velocities and accelerations, the J and receive buffers, a communication stream and the events between
+ * it and ctx's launch stream. `comm` may be NULL when world == 1. The schedule follows ctx's kernel at creation. */
+int nbody_shard_create(nbody_shard** out, nbody_ctx* ctx, int rank, int world, int n_total, const nbody_comm* comm);
+int nbody_shard_destroy(nbody_shard* shard);
+int nbody_shard_get_plan(nbody_shard* shard, nbody_shard_plan_t* out);
+/* Device pointers of the rank's arrays (x: n_pad bodies, v/a: shard bodies, jbuf/rbuf as in the plan) for callers that
+ * wrap them (torch) or fill them on the device. Any out pointer may be NULL. */
+int nbody_shard_buffers(nbody_shard* shard, nbody_float4** d_x_full, nbody_float4** d_v_own, nbody_float4** d_a_own,
+                        nbody_float4** d_jbuf, nbody_float4** d_rbuf);
+/* Every rank passes the same n_total bodies (host memory): positions of all, zero velocity/acceleration; padding
+ * bodies are massless and sit on body 0. Synchronous. */
+int nbody_shard_upload(nbody_shard* shard, const nbody_float4* h_bodies);
+/* Own block (shard entries each, padding included) to host memory. Synchronous. */
+int nbody_shard_download(nbody_shard* shard, nbody_float4* h_x_own, nbody_float4* h_v_own, nbody_float4* h_a_own);
+/* `steps` whole steps, asynchronous (nbody_shard_sync waits for both streams). */
+int nbody_shard_step(nbody_shard* shard, int steps);
+/* One step in four parts, for a driver that holds several ranks in one thread (tests): 0 = start the all-gather,
+ * 1 = force launches, 2 = start the exchange, 3 = add received sums + integrate. nbody_shard_step = 0,1,2,3 per step. */
+int nbody_shard_step_phase(nbody_shard* shard, int phase);
+int nbody_shard_sync(nbody_shard* shard);
+/* Per-step communication timing (events on the two streams): mean all-gather time and the part of it not hidden
+ * behind the own-block pass; mean exchange time (exposed by construction). Any out pointer may be NULL. */
+int nbody_shard_comm_timing(nbody_shard* shard, int enable);
+int nbody_shard_comm_report(nbody_shard* shard, int* steps, double* gather_ms, double* gather_exposed_ms, double* exchange_ms);
+
 /* ---- fp64 variant (the build's own; the reference has no double path) -------------------- */
 int nbody_step_f64(nbody_ctx* ctx, nbody_double4* d_bodies, nbody_double4* d_accelerations,
                    nbody_double4* d_velocity, int n, int steps, double dt, double eps2);

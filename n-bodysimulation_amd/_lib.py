@@ -36,6 +36,37 @@ class NBodyError(RuntimeError):
         self.code = code
 
 
+SCHEDULE_CANONICAL = 0   # strict kernel: own targets x [0, n) in index order
+SCHEDULE_ONESIDED = 1    # own x own while gathering, then own x everybody else (one wrapped launch)
+SCHEDULE_SYMMETRIC = 2   # every unordered pair once in the machine; J-side sums sent to their owners
+MAX_RANKS = 64
+
+
+class CrossLaunch(C.Structure):   # nbody_cross_launch
+    _fields_ = [("i0", C.c_int), ("i1", C.c_int), ("j0", C.c_int), ("count", C.c_int), ("jbuf_offset", C.c_int)]
+
+
+class Segment(C.Structure):       # nbody_shard_segment
+    _fields_ = [("peer", C.c_int), ("offset", C.c_int), ("count", C.c_int), ("body0", C.c_int)]
+
+
+class ShardPlan(C.Structure):     # nbody_shard_plan_t
+    _fields_ = [("rank", C.c_int), ("world", C.c_int), ("n_total", C.c_int), ("schedule", C.c_int),
+                ("shard", C.c_int), ("n_pad", C.c_int), ("i0", C.c_int), ("i1", C.c_int),
+                ("n_launches", C.c_int), ("launch", CrossLaunch * 2), ("jbuf_bodies", C.c_int),
+                ("n_sends", C.c_int), ("n_recvs", C.c_int), ("send", Segment * MAX_RANKS), ("recv", Segment * MAX_RANKS),
+                ("rbuf_bodies", C.c_int)]
+
+
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(Segment), C.c_int, C.c_void_p, C.POINTER(Segment), C.c_int,
+                          C.c_void_p, C.c_void_p)
+
+
+class Comm(C.Structure):          # nbody_comm
+    _fields_ = [("user", C.c_void_p), ("all_gather", ALL_GATHER_FN), ("exchange", EXCHANGE_FN)]
+
+
 # every symbol include/nbody.h declares, with its signature
 _p = C.c_void_p
 _SIGNATURES = {
@@ -56,6 +87,22 @@ _SIGNATURES = {
     "nbody_accel_cross": (C.c_int, [_p, _p, C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "nbody_integrate_range": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int]),
     "nbody_ctx_sync": (C.c_int, [_p]),
+    "nbody_ctx_get": (C.c_int, [_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_p)]),
+    "nbody_shard_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(ShardPlan)]),
+    "nbody_comm_rccl_unique_id": (C.c_int, [_p]),
+    "nbody_comm_rccl_create": (C.c_int, [C.POINTER(Comm), C.c_int, C.c_int, _p]),
+    "nbody_comm_rccl_destroy": (C.c_int, [C.POINTER(Comm)]),
+    "nbody_shard_create": (C.c_int, [C.POINTER(_p), _p, C.c_int, C.c_int, C.c_int, C.POINTER(Comm)]),
+    "nbody_shard_destroy": (C.c_int, [_p]),
+    "nbody_shard_get_plan": (C.c_int, [_p, C.POINTER(ShardPlan)]),
+    "nbody_shard_buffers": (C.c_int, [_p] + [C.POINTER(_p)] * 5),
+    "nbody_shard_upload": (C.c_int, [_p, _p]),
+    "nbody_shard_download": (C.c_int, [_p, _p, _p, _p]),
+    "nbody_shard_step": (C.c_int, [_p, C.c_int]),
+    "nbody_shard_step_phase": (C.c_int, [_p, C.c_int]),
+    "nbody_shard_sync": (C.c_int, [_p]),
+    "nbody_shard_comm_timing": (C.c_int, [_p, C.c_int]),
+    "nbody_shard_comm_report": (C.c_int, [_p, C.POINTER(C.c_int)] + [C.POINTER(C.c_double)] * 3),
     "nbody_ctx_timing": (C.c_int, [_p, C.c_int]),
     "nbody_ctx_timing_read": (C.c_int, [_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "nbody_step_f64": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_double, C.c_double]),

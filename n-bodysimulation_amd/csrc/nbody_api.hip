@@ -22,10 +22,11 @@ static_assert(sizeof(nbody_float4) == sizeof(float4) && alignof(float4) == 16, "
 static_assert(sizeof(nbody_double4) == sizeof(double4), "double4 layout");
 
 namespace {
-
 thread_local char g_err[512] = "";
+}
 
-int fail(int code, const char* fmt, ...)
+// records the calling thread's error message (also used by nbody_shard.hip); returns `code`
+__attribute__((visibility("hidden"))) int nbody_fail(int code, const char* fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
@@ -33,6 +34,10 @@ int fail(int code, const char* fmt, ...)
     va_end(ap);
     return code;
 }
+
+namespace {
+
+#define fail nbody_fail
 
 #define HIP_TRY(expr)                                                                       \
     do {                                                                                    \
@@ -884,6 +889,15 @@ int nbody_ctx_sync(nbody_ctx* c)
 {
     if (int rc = check_ctx(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return NBODY_OK;
+}
+
+int nbody_ctx_get(nbody_ctx* c, int* device, int* kernel, void** hip_stream)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (device) *device = c->device;
+    if (kernel) *kernel = c->kernel;
+    if (hip_stream) *hip_stream = static_cast<void*>(c->stream);
     return NBODY_OK;
 }
 

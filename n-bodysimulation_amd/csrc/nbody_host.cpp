@@ -103,6 +103,106 @@ int nbody_fill_seeded(nbody_float4* b, int n, int init, unsigned long long seed)
     return NBODY_ERR_INVALID;
 }
 
+// ---- sharded step: who evaluates which pairs, and who owes whom which sums (pure host logic) -------------
+
+}  // extern "C"
+
+namespace {
+
+// the cross launches of rank q (symmetric schedule): every unordered pair of blocks {a, b}, a != b, is taken by
+// exactly one rank — rank a for b = a+1 .. a+(G-1)/2 (mod G); for an even G the pair {q, q+G/2} is shared:
+// the lower rank takes the lower half of the upper rank's block, the upper rank takes the rest with its own
+// upper half as targets.
+int cross_launches(int q, int G, int S, nbody_cross_launch out[2])
+{
+    const int n_pad = G * S;
+    int n = 0, off = 0;
+    auto add = [&](int i0, int i1, int j0, int count) {
+        if (count <= 0 || i1 <= i0) return;
+        out[n].i0 = i0; out[n].i1 = i1; out[n].j0 = j0 % n_pad; out[n].count = count; out[n].jbuf_offset = off;
+        off += count;
+        ++n;
+    };
+    const int own0 = q * S, own1 = own0 + S;
+    if (G % 2 == 1) {
+        add(own0, own1, own1, ((G - 1) / 2) * S);
+    } else {
+        const int full = G / 2 - 1;
+        if (q < G / 2) {
+            add(own0, own1, own1, full * S + S / 2);
+        } else {
+            add(own0, own1, own1, full * S);
+            add(own0 + S / 2, own1, (q - G / 2) * S, S);
+        }
+    }
+    return n;
+}
+
+int send_segments(int q, int G, int S, nbody_shard_segment* out)
+{
+    nbody_cross_launch L[2];
+    const int nl = cross_launches(q, G, S, L);
+    const int n_pad = G * S;
+    int n = 0;
+    for (int l = 0; l < nl; ++l) {
+        int pos = 0;
+        while (pos < L[l].count) {
+            const int abs0 = (L[l].j0 + pos) % n_pad;
+            const int owner = abs0 / S;
+            int len = (owner + 1) * S - abs0;
+            if (len > L[l].count - pos) len = L[l].count - pos;
+            out[n].peer = owner;
+            out[n].offset = L[l].jbuf_offset + pos;
+            out[n].count = len;
+            out[n].body0 = abs0;
+            ++n;
+            pos += len;
+        }
+    }
+    return n;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nbody_shard_plan(int rank, int world, int n_total, int schedule, nbody_shard_plan_t* p)
+{
+    if (!p || world < 1 || world > NBODY_MAX_RANKS || rank < 0 || rank >= world || n_total < 0) return NBODY_ERR_INVALID;
+    if (schedule != NBODY_SCHEDULE_CANONICAL && schedule != NBODY_SCHEDULE_ONESIDED && schedule != NBODY_SCHEDULE_SYMMETRIC)
+        return NBODY_ERR_INVALID;
+    *p = nbody_shard_plan_t{};
+    p->rank = rank; p->world = world; p->n_total = n_total; p->schedule = schedule;
+    int S = (n_total + world - 1) / world;
+    if (S & 1) ++S;  // even, so that the block half-way round an even ring can be split between its two ranks
+    if ((long)S * world > 2147483647L) return NBODY_ERR_INVALID;
+    p->shard = S;
+    p->n_pad = S * world;
+    p->i0 = rank * S;
+    p->i1 = p->i0 + S;
+    if (schedule != NBODY_SCHEDULE_SYMMETRIC || world == 1 || S == 0) return NBODY_OK;
+    p->n_launches = cross_launches(rank, world, S, p->launch);
+    for (int l = 0; l < p->n_launches; ++l) p->jbuf_bodies += p->launch[l].count;
+    p->n_sends = send_segments(rank, world, S, p->send);
+    // what arrives: every other rank's segments addressed to this one, nearest preceding rank first (the order in
+    // which the sums are added — fixed, so the result does not depend on arrival times)
+    nbody_shard_segment tmp[NBODY_MAX_RANKS];
+    for (int d = 1; d < world; ++d) {
+        const int q = (rank - d + world) % world;
+        const int ns = send_segments(q, world, S, tmp);
+        for (int k = 0; k < ns; ++k) {
+            if (tmp[k].peer != rank) continue;
+            nbody_shard_segment& r = p->recv[p->n_recvs++];
+            r.peer = q;
+            r.offset = p->rbuf_bodies;
+            r.count = tmp[k].count;
+            r.body0 = tmp[k].body0;
+            p->rbuf_bodies += tmp[k].count;
+        }
+    }
+    return NBODY_OK;
+}
+
 // validation.cpp:143-164 as a count
 int nbody_verify_still_bodies(const nbody_float4* v, const nbody_float4* x, int n)
 {

@@ -1,0 +1,508 @@
+// nbody_shard.hip — one rank of the sharded (multi-GPU) step behind the C-ABI (include/nbody.h, "sharded step"),
+// and the RCCL implementation of its two collectives. The reference runs on one device only
+// (TestProject/kernel.cu:630, main.cpp:287); this is the build's own decomposition. The pair
+// arithmetic is entirely nbody_accel_range / nbody_accel_wrapped / nbody_accel_cross / nbody_integrate_range of
+// nbody_api.hip: this file only orders them on two streams.
+#include "nbody.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+int nbody_fail(int code, const char* fmt, ...);  // nbody_api.hip
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return nbody_fail(NBODY_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                              __FILE__, __LINE__);                                                 \
+    } while (0)
+
+namespace {
+
+struct DeviceScope {
+    int prev = -1;
+    bool changed = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int device)
+    {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) {
+            err = hipSetDevice(device);
+            changed = (err == hipSuccess);
+        }
+    }
+    ~DeviceScope()
+    {
+        if (changed) (void)hipSetDevice(prev);
+    }
+};
+
+// a[k] += b[k], individually rounded adds (the received partial sums are added in the plan's fixed order)
+__global__ void __launch_bounds__(256) add_bodies(float4* a, const float4* b, int n)
+{
+#pragma clang fp contract(off)
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    float4 p = a[k];
+    const float4 q = b[k];
+    p.x += q.x; p.y += q.y; p.z += q.z;
+    a[k] = p;
+}
+
+}  // namespace
+
+struct nbody_shard {
+    nbody_ctx* ctx = nullptr;
+    int device = 0;
+    hipStream_t compute = nullptr;  // the context's launch stream
+    hipStream_t comm = nullptr;     // own
+    nbody_comm cb{};
+    bool have_comm = false;
+    nbody_shard_plan_t plan{};
+    float4 *x = nullptr, *v = nullptr, *a = nullptr, *jbuf = nullptr, *rbuf = nullptr;
+    hipEvent_t ev_integrated = nullptr, ev_gathered = nullptr, ev_cross = nullptr, ev_exchanged = nullptr;
+    bool fresh = true;          // positions consistent on every rank (just uploaded): the first step skips the all-gather
+    bool gather_posted = false;
+    // communication timing
+    bool timing = false;
+    struct StepEvents {
+        hipEvent_t g0, g1, local_done, x0, x1;
+        bool gathered, exchanged;
+    };
+    std::vector<StepEvents> timed;
+};
+
+namespace {
+
+int new_event(hipEvent_t* e, bool timing)
+{
+    HIP_TRY(hipEventCreateWithFlags(e, timing ? hipEventDefault : hipEventDisableTiming));
+    return NBODY_OK;
+}
+
+int check_shard(const nbody_shard* s)
+{
+    if (!s) return nbody_fail(NBODY_ERR_INVALID, "null shard");
+    return NBODY_OK;
+}
+
+nbody_float4* nb(float4* p) { return reinterpret_cast<nbody_float4*>(p); }
+
+int phase_gather(nbody_shard* s)
+{
+    const nbody_shard_plan_t& p = s->plan;
+    s->gather_posted = false;
+    if (s->timing) {
+        nbody_shard::StepEvents ev{};
+        for (hipEvent_t* e : {&ev.g0, &ev.g1, &ev.local_done, &ev.x0, &ev.x1})
+            if (int rc = new_event(e, true)) return rc;
+        s->timed.push_back(ev);
+    }
+    if (p.world == 1 || s->fresh) return NBODY_OK;
+    HIP_TRY(hipStreamWaitEvent(s->comm, s->ev_integrated, 0));  // the own block was advanced by the last integrate
+    if (s->timing) HIP_TRY(hipEventRecord(s->timed.back().g0, s->comm));
+    if (s->cb.all_gather(s->cb.user, nb(s->x), p.shard, static_cast<void*>(s->comm)) != 0)
+        return nbody_fail(NBODY_ERR_HIP, "all-gather callback failed on rank %d", p.rank);
+    if (s->timing) {
+        HIP_TRY(hipEventRecord(s->timed.back().g1, s->comm));
+        s->timed.back().gathered = true;
+    }
+    HIP_TRY(hipEventRecord(s->ev_gathered, s->comm));
+    s->gather_posted = true;
+    return NBODY_OK;
+}
+
+int phase_compute(nbody_shard* s)
+{
+    const nbody_shard_plan_t& p = s->plan;
+    nbody_ctx* c = s->ctx;
+    if (p.shard == 0) return NBODY_OK;
+    if (p.schedule == NBODY_SCHEDULE_CANONICAL) {
+        if (s->gather_posted) HIP_TRY(hipStreamWaitEvent(s->compute, s->ev_gathered, 0));
+        return nbody_accel_range(c, nb(s->x), nb(s->a), p.i0, p.i1, 0, p.n_pad, 0);
+    }
+    // own block against itself while the positions of the others are still on their way
+    if (int rc = nbody_accel_range(c, nb(s->x), nb(s->a), p.i0, p.i1, p.i0, p.i1, 0)) return rc;
+    if (s->timing && s->gather_posted) HIP_TRY(hipEventRecord(s->timed.back().local_done, s->compute));
+    if (s->gather_posted) HIP_TRY(hipStreamWaitEvent(s->compute, s->ev_gathered, 0));
+    if (p.world == 1) return NBODY_OK;
+    if (p.schedule == NBODY_SCHEDULE_ONESIDED)  // everybody else in one launch: sources i1, i1+1, ... wrapping round to i0-1
+        return nbody_accel_wrapped(c, nb(s->x), p.n_pad, nb(s->a), p.i0, p.i1, p.i1 % p.n_pad, p.n_pad - p.shard, 1);
+    for (int l = 0; l < p.n_launches; ++l) {
+        const nbody_cross_launch& L = p.launch[l];
+        if (int rc = nbody_accel_cross(c, nb(s->x), p.n_pad, nb(s->a + (L.i0 - p.i0)), L.i0, L.i1, 1, L.j0, L.count,
+                                       nb(s->jbuf + L.jbuf_offset)))
+            return rc;
+    }
+    HIP_TRY(hipEventRecord(s->ev_cross, s->compute));
+    return NBODY_OK;
+}
+
+int phase_exchange(nbody_shard* s)
+{
+    const nbody_shard_plan_t& p = s->plan;
+    if (p.world == 1 || p.schedule != NBODY_SCHEDULE_SYMMETRIC || p.shard == 0) return NBODY_OK;
+    HIP_TRY(hipStreamWaitEvent(s->comm, s->ev_cross, 0));
+    if (s->timing) HIP_TRY(hipEventRecord(s->timed.back().x0, s->comm));
+    if (s->cb.exchange(s->cb.user, p.send, p.n_sends, nb(s->jbuf), p.recv, p.n_recvs, nb(s->rbuf), static_cast<void*>(s->comm)) != 0)
+        return nbody_fail(NBODY_ERR_HIP, "exchange callback failed on rank %d", p.rank);
+    if (s->timing) {
+        HIP_TRY(hipEventRecord(s->timed.back().x1, s->comm));
+        s->timed.back().exchanged = true;
+    }
+    HIP_TRY(hipEventRecord(s->ev_exchanged, s->comm));
+    return NBODY_OK;
+}
+
+int phase_finish(nbody_shard* s)
+{
+    const nbody_shard_plan_t& p = s->plan;
+    if (p.shard == 0) return NBODY_OK;
+    if (p.world > 1 && p.schedule == NBODY_SCHEDULE_SYMMETRIC) {
+        HIP_TRY(hipStreamWaitEvent(s->compute, s->ev_exchanged, 0));
+        for (int k = 0; k < p.n_recvs; ++k) {  // fixed order: nearest preceding rank first
+            const nbody_shard_segment& r = p.recv[k];
+            add_bodies<<<(r.count + 255) / 256, 256, 0, s->compute>>>(s->a + (r.body0 - p.i0), s->rbuf + r.offset, r.count);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    if (int rc = nbody_integrate_range(s->ctx, nb(s->x), nb(s->v), nb(s->a), p.i0, p.i1)) return rc;
+    HIP_TRY(hipEventRecord(s->ev_integrated, s->compute));
+    s->fresh = false;
+    return NBODY_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nbody_shard_create(nbody_shard** out, nbody_ctx* ctx, int rank, int world, int n_total, const nbody_comm* comm)
+{
+    if (!out) return nbody_fail(NBODY_ERR_INVALID, "null out");
+    *out = nullptr;
+    int device = 0, kernel = 0;
+    void* stream = nullptr;
+    if (int rc = nbody_ctx_get(ctx, &device, &kernel, &stream)) return rc;
+    if (world > 1 && (!comm || !comm->all_gather || !comm->exchange))
+        return nbody_fail(NBODY_ERR_INVALID, "world=%d needs both communication callbacks", world);
+    const int schedule = kernel == NBODY_KERNEL_STRICT ? NBODY_SCHEDULE_CANONICAL
+                         : kernel == NBODY_KERNEL_ONESIDED ? NBODY_SCHEDULE_ONESIDED : NBODY_SCHEDULE_SYMMETRIC;
+    nbody_shard* s = new (std::nothrow) nbody_shard();
+    if (!s) return nbody_fail(NBODY_ERR_NOMEM, "out of host memory");
+    if (nbody_shard_plan(rank, world, n_total, schedule, &s->plan) != NBODY_OK) {
+        delete s;
+        return nbody_fail(NBODY_ERR_INVALID, "bad shard geometry: rank %d of %d, %d bodies", rank, world, n_total);
+    }
+    s->ctx = ctx;
+    s->device = device;
+    s->compute = static_cast<hipStream_t>(stream);
+    if (comm) { s->cb = *comm; s->have_comm = true; }
+    DeviceScope scope(device);
+    const nbody_shard_plan_t& p = s->plan;
+    auto cleanup = [&](int rc) { nbody_shard_destroy(s); return rc; };
+    auto alloc = [&](float4** ptr, size_t bodies) -> int {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(ptr), (bodies ? bodies : 1) * sizeof(float4)));
+        HIP_TRY(hipMemset(*ptr, 0, (bodies ? bodies : 1) * sizeof(float4)));
+        return NBODY_OK;
+    };
+    if (int rc = alloc(&s->x, p.n_pad)) return cleanup(rc);
+    if (int rc = alloc(&s->v, p.shard)) return cleanup(rc);
+    if (int rc = alloc(&s->a, p.shard)) return cleanup(rc);
+    if (int rc = alloc(&s->jbuf, p.jbuf_bodies)) return cleanup(rc);
+    if (int rc = alloc(&s->rbuf, p.rbuf_bodies)) return cleanup(rc);
+    hipError_t e = hipStreamCreateWithFlags(&s->comm, hipStreamNonBlocking);
+    if (e != hipSuccess) return cleanup(nbody_fail(NBODY_ERR_HIP, "hipStreamCreateWithFlags failed: %s", hipGetErrorString(e)));
+    for (hipEvent_t* ev : {&s->ev_integrated, &s->ev_gathered, &s->ev_cross, &s->ev_exchanged})
+        if (int rc = new_event(ev, false)) return cleanup(rc);
+    e = hipDeviceSynchronize();  // the zero fills above ran on the null stream
+    if (e != hipSuccess) return cleanup(nbody_fail(NBODY_ERR_HIP, "hipDeviceSynchronize failed: %s", hipGetErrorString(e)));
+    // size the context's slab workspace once, for the largest launch of this rank
+    if (p.shard > 0) (void)nbody_ctx_reserve(ctx, p.shard);
+    *out = s;
+    return NBODY_OK;
+}
+
+int nbody_shard_destroy(nbody_shard* s)
+{
+    if (!s) return NBODY_OK;
+    DeviceScope scope(s->device);
+    if (s->compute) (void)hipStreamSynchronize(s->compute);
+    if (s->comm) (void)hipStreamSynchronize(s->comm);
+    for (float4* ptr : {s->x, s->v, s->a, s->jbuf, s->rbuf})
+        if (ptr) (void)hipFree(ptr);
+    for (hipEvent_t ev : {s->ev_integrated, s->ev_gathered, s->ev_cross, s->ev_exchanged})
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto& t : s->timed)
+        for (hipEvent_t ev : {t.g0, t.g1, t.local_done, t.x0, t.x1})
+            if (ev) (void)hipEventDestroy(ev);
+    if (s->comm) (void)hipStreamDestroy(s->comm);
+    delete s;
+    return NBODY_OK;
+}
+
+int nbody_shard_get_plan(nbody_shard* s, nbody_shard_plan_t* out)
+{
+    if (int rc = check_shard(s)) return rc;
+    if (!out) return nbody_fail(NBODY_ERR_INVALID, "null out");
+    *out = s->plan;
+    return NBODY_OK;
+}
+
+int nbody_shard_buffers(nbody_shard* s, nbody_float4** d_x_full, nbody_float4** d_v_own, nbody_float4** d_a_own,
+                        nbody_float4** d_jbuf, nbody_float4** d_rbuf)
+{
+    if (int rc = check_shard(s)) return rc;
+    if (d_x_full) *d_x_full = nb(s->x);
+    if (d_v_own) *d_v_own = nb(s->v);
+    if (d_a_own) *d_a_own = nb(s->a);
+    if (d_jbuf) *d_jbuf = nb(s->jbuf);
+    if (d_rbuf) *d_rbuf = nb(s->rbuf);
+    return NBODY_OK;
+}
+
+int nbody_shard_upload(nbody_shard* s, const nbody_float4* h_bodies)
+{
+    if (int rc = check_shard(s)) return rc;
+    const nbody_shard_plan_t& p = s->plan;
+    if (p.n_total > 0 && !h_bodies) return nbody_fail(NBODY_ERR_INVALID, "null host pointer");
+    DeviceScope scope(s->device);
+    HIP_TRY(hipStreamSynchronize(s->compute));
+    HIP_TRY(hipStreamSynchronize(s->comm));
+    std::vector<nbody_float4> padded((size_t)p.n_pad);
+    if (p.n_total > 0) std::memcpy(padded.data(), h_bodies, (size_t)p.n_total * sizeof(nbody_float4));
+    for (int i = p.n_total; i < p.n_pad; ++i) {  // massless, on top of body 0: adds exactly +-0 to every sum
+        padded[i] = p.n_total > 0 ? h_bodies[0] : nbody_float4{0, 0, 0, 0};
+        padded[i].w = 0.0f;
+    }
+    if (p.n_pad > 0) HIP_TRY(hipMemcpy(s->x, padded.data(), (size_t)p.n_pad * sizeof(float4), hipMemcpyHostToDevice));
+    if (p.shard > 0) {
+        HIP_TRY(hipMemset(s->v, 0, (size_t)p.shard * sizeof(float4)));
+        HIP_TRY(hipMemset(s->a, 0, (size_t)p.shard * sizeof(float4)));
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    s->fresh = true;
+    return NBODY_OK;
+}
+
+int nbody_shard_download(nbody_shard* s, nbody_float4* h_x_own, nbody_float4* h_v_own, nbody_float4* h_a_own)
+{
+    if (int rc = check_shard(s)) return rc;
+    const nbody_shard_plan_t& p = s->plan;
+    DeviceScope scope(s->device);
+    HIP_TRY(hipStreamSynchronize(s->compute));
+    HIP_TRY(hipStreamSynchronize(s->comm));
+    const size_t bytes = (size_t)p.shard * sizeof(float4);
+    if (bytes == 0) return NBODY_OK;
+    if (h_x_own) HIP_TRY(hipMemcpy(h_x_own, s->x + p.i0, bytes, hipMemcpyDeviceToHost));
+    if (h_v_own) HIP_TRY(hipMemcpy(h_v_own, s->v, bytes, hipMemcpyDeviceToHost));
+    if (h_a_own) HIP_TRY(hipMemcpy(h_a_own, s->a, bytes, hipMemcpyDeviceToHost));
+    return NBODY_OK;
+}
+
+int nbody_shard_step_phase(nbody_shard* s, int phase)
+{
+    if (int rc = check_shard(s)) return rc;
+    DeviceScope scope(s->device);
+    switch (phase) {
+        case 0: return phase_gather(s);
+        case 1: return phase_compute(s);
+        case 2: return phase_exchange(s);
+        case 3: return phase_finish(s);
+        default: return nbody_fail(NBODY_ERR_INVALID, "phase must be 0..3 (got %d)", phase);
+    }
+}
+
+int nbody_shard_step(nbody_shard* s, int steps)
+{
+    if (int rc = check_shard(s)) return rc;
+    if (steps < 0) return nbody_fail(NBODY_ERR_INVALID, "steps=%d", steps);
+    DeviceScope scope(s->device);
+    for (int k = 0; k < steps; ++k) {
+        if (int rc = phase_gather(s)) return rc;
+        if (int rc = phase_compute(s)) return rc;
+        if (int rc = phase_exchange(s)) return rc;
+        if (int rc = phase_finish(s)) return rc;
+    }
+    return NBODY_OK;
+}
+
+int nbody_shard_sync(nbody_shard* s)
+{
+    if (int rc = check_shard(s)) return rc;
+    DeviceScope scope(s->device);
+    HIP_TRY(hipStreamSynchronize(s->compute));
+    HIP_TRY(hipStreamSynchronize(s->comm));
+    return NBODY_OK;
+}
+
+int nbody_shard_comm_timing(nbody_shard* s, int enable)
+{
+    if (int rc = check_shard(s)) return rc;
+    if (int rc = nbody_shard_sync(s)) return rc;
+    for (auto& t : s->timed)
+        for (hipEvent_t ev : {t.g0, t.g1, t.local_done, t.x0, t.x1})
+            if (ev) (void)hipEventDestroy(ev);
+    s->timed.clear();
+    s->timing = enable != 0;
+    return NBODY_OK;
+}
+
+int nbody_shard_comm_report(nbody_shard* s, int* steps, double* gather_ms, double* gather_exposed_ms, double* exchange_ms)
+{
+    if (int rc = check_shard(s)) return rc;
+    if (int rc = nbody_shard_sync(s)) return rc;
+    double g = 0, ge = 0, x = 0;
+    int ng = 0, nx = 0;
+    for (auto& t : s->timed) {
+        float ms = 0;
+        if (t.gathered) {
+            HIP_TRY(hipEventElapsedTime(&ms, t.g0, t.g1));
+            g += ms;
+            // not hidden = from the end of the own-block pass to the end of the all-gather (0 when the gather ended first)
+            if (hipEventElapsedTime(&ms, t.local_done, t.g1) == hipSuccess && ms > 0) ge += ms;
+            ++ng;
+        }
+        if (t.exchanged) {
+            HIP_TRY(hipEventElapsedTime(&ms, t.x0, t.x1));
+            x += ms;
+            ++nx;
+        }
+    }
+    if (steps) *steps = (int)s->timed.size();
+    if (gather_ms) *gather_ms = ng ? g / ng : 0.0;
+    if (gather_exposed_ms) *gather_exposed_ms = ng ? ge / ng : 0.0;
+    if (exchange_ms) *exchange_ms = nx ? x / nx : 0.0;
+    return NBODY_OK;
+}
+
+// ---- RCCL (librccl.so, loaded on first use) -------------------------------------------------------------------------
+
+namespace {
+
+struct RcclId { char internal[128]; };  // ncclUniqueId
+typedef void* RcclComm;                 // ncclComm_t
+enum { kRcclFloat = 7 };                // ncclFloat32
+
+struct RcclApi {
+    void* handle = nullptr;
+    int (*GetUniqueId)(RcclId*) = nullptr;
+    int (*CommInitRank)(RcclComm*, int, RcclId, int) = nullptr;
+    int (*CommDestroy)(RcclComm) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
+    int (*Send)(const void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+
+RcclApi g_rccl;
+
+int rccl_load()
+{
+    if (g_rccl.handle) return NBODY_OK;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return nbody_fail(NBODY_ERR_HIP, "cannot load librccl.so: %s", dlerror());
+    RcclApi api;
+    api.handle = h;
+    bool ok = true;
+    auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) ok = false; return p; };
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+    api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+    api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
+    api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
+    api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+    api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!ok) return nbody_fail(NBODY_ERR_HIP, "librccl.so lacks an expected ncclXxx symbol");
+    g_rccl = api;
+    return NBODY_OK;
+}
+
+struct RcclUser {
+    RcclComm comm = nullptr;
+    int rank = 0, world = 1;
+};
+
+int rccl_all_gather(void* user, nbody_float4* d_x_full, int bodies_per_rank, void* hip_stream)
+{
+    RcclUser* u = static_cast<RcclUser*>(user);
+    const size_t count = (size_t)bodies_per_rank * 4;  // floats per rank
+    const float* send = reinterpret_cast<const float*>(d_x_full) + (size_t)u->rank * count;  // in place
+    return g_rccl.AllGather(send, d_x_full, count, kRcclFloat, u->comm, static_cast<hipStream_t>(hip_stream));
+}
+
+int rccl_exchange(void* user, const nbody_shard_segment* send, int n_sends, const nbody_float4* d_jbuf,
+                  const nbody_shard_segment* recv, int n_recvs, nbody_float4* d_rbuf, void* hip_stream)
+{
+    RcclUser* u = static_cast<RcclUser*>(user);
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    int rc = g_rccl.GroupStart();
+    for (int k = 0; k < n_sends && rc == 0; ++k)
+        rc = g_rccl.Send(d_jbuf + send[k].offset, (size_t)send[k].count * 4, kRcclFloat, send[k].peer, u->comm, st);
+    for (int k = 0; k < n_recvs && rc == 0; ++k)
+        rc = g_rccl.Recv(d_rbuf + recv[k].offset, (size_t)recv[k].count * 4, kRcclFloat, recv[k].peer, u->comm, st);
+    const int rc2 = g_rccl.GroupEnd();
+    return rc ? rc : rc2;
+}
+
+}  // namespace
+
+int nbody_comm_rccl_unique_id(void* out_128_bytes)
+{
+    if (!out_128_bytes) return nbody_fail(NBODY_ERR_INVALID, "null out");
+    if (int rc = rccl_load()) return rc;
+    RcclId id;
+    const int rc = g_rccl.GetUniqueId(&id);
+    if (rc != 0) return nbody_fail(NBODY_ERR_HIP, "ncclGetUniqueId failed: %s", g_rccl.GetErrorString(rc));
+    std::memcpy(out_128_bytes, &id, sizeof id);
+    return NBODY_OK;
+}
+
+int nbody_comm_rccl_create(nbody_comm* out, int rank, int world, const void* unique_id_128_bytes)
+{
+    if (!out || !unique_id_128_bytes) return nbody_fail(NBODY_ERR_INVALID, "null argument");
+    if (world < 1 || rank < 0 || rank >= world) return nbody_fail(NBODY_ERR_INVALID, "rank %d of %d", rank, world);
+    if (int rc = rccl_load()) return rc;
+    RcclUser* u = new (std::nothrow) RcclUser();
+    if (!u) return nbody_fail(NBODY_ERR_NOMEM, "out of host memory");
+    u->rank = rank;
+    u->world = world;
+    RcclId id;
+    std::memcpy(&id, unique_id_128_bytes, sizeof id);
+    const int rc = g_rccl.CommInitRank(&u->comm, world, id, rank);  // the communicator lives on the CURRENT device
+    if (rc != 0) {
+        delete u;
+        return nbody_fail(NBODY_ERR_HIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(rc));
+    }
+    out->user = u;
+    out->all_gather = rccl_all_gather;
+    out->exchange = rccl_exchange;
+    return NBODY_OK;
+}
+
+int nbody_comm_rccl_destroy(nbody_comm* comm)
+{
+    if (!comm || !comm->user) return NBODY_OK;
+    RcclUser* u = static_cast<RcclUser*>(comm->user);
+    if (u->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(u->comm);
+    delete u;
+    comm->user = nullptr;
+    comm->all_gather = nullptr;
+    comm->exchange = nullptr;
+    return NBODY_OK;
+}
+
+}  // extern "C"

@@ -1,32 +1,32 @@
-"""Multi-GPU step: bodies block-partitioned over the ranks of one node, one all-gather of
-positions per step, overlapped with the local-block force pass.
+"""Multi-GPU step: bodies block-partitioned over the ranks of one node (one process per GPU).
 
-The reference is single-device (device 0 hard-coded: TestProject/kernel.cu:630); this is the
-build's own decomposition:
+The reference is single-device (TestProject/kernel.cu:630, main.cpp:287); this is the build's own
+decomposition. The step itself is native: ``nbody_shard_*`` in libnbody_hip.so
+(csrc/nbody_shard.hip) owns the rank's device arrays, the compute and communication streams and the
+events between them, and orders the C-ABI force/integrate launches. This module is the thin host
+side: it asks the library for the rank's plan, hands it the two collectives as callbacks over
+``torch.distributed`` (backend "nccl" is RCCL on ROCm, over xGMI) and moves state in and out.
 
-    rank r owns the contiguous index block [r*S, (r+1)*S), S = ceil(N / G)
-    every rank holds the whole position/mass array X_full (16 B/body: 16 MiB at N = 1 M)
-    V and A of the own block never leave the rank
+    rank r owns the contiguous index block [r*S, (r+1)*S); every rank holds all positions
+    (16 B/body: 16 MiB at N = 1 M); velocities and accelerations never leave the rank.
 
-    per step, on rank r                        stream
-      all_gather(X_full <- own block)            comm     (in place, S*16 B per rank)
-      A  = forces(own targets, own sources)      compute  (overlaps the all-gather)
-      wait(all_gather)
-      A += forces(own targets, all other blocks: sources i1, i1+1, ... wrapping around to i0-1)
-      v += (dt/2) a ; x += dt v  (own block)     compute
-      -> event for the next step's all-gather
+    per step, on rank r (schedule SYMMETRIC, the default)          stream
+      all_gather(X_full <- own block), in place, S*16 B per rank     comm     | overlapped
+      A  = own block x own block, every unordered pair once          compute  |
+      A += own block x blocks r+1 .. r+(G-1)/2 (mod G), pairs once   compute  -> J-side sums for OTHER ranks
+      exchange: J-side sums to their owners, mine arrive             comm     (grouped send/recv)
+      A += received sums (fixed order); v += (dt/2) a ; x += dt v    compute
 
-The remote pass of step n ends before the integrate of step n (same stream), and the
-all-gather of step n+1 waits on that integrate, so no second position buffer is needed.
+so every unordered pair of bodies is evaluated exactly once in the whole machine. With the ONESIDED
+kernel a rank evaluates its targets against all N sources (no exchange); with the STRICT kernel it
+does so in index order, bit-identical to the single-device strict step.
 
-One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, over xGMI). All compute
-goes through a *backend*: ``HipBackend`` (the C-ABI, the only backend the product ships).
-``tests/`` inject a CPU checker backend to exercise this schedule under ``gloo`` without a GPU.
-Padding bodies (when G does not divide N) are massless and sit on the first body, so they add
-exactly +-0 to every sum.
+``shard_plan`` (pure host logic of the library) and ``TorchComm`` also work without a GPU: the CPU
+tests drive the same plan and the same collectives under gloo with the checker as compute.
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Optional
 
 import numpy as np
@@ -34,7 +34,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
-from ._lib import KERNEL_FAST
+from ._lib import KERNEL_FAST, SCHEDULE_CANONICAL, SCHEDULE_ONESIDED, SCHEDULE_SYMMETRIC, check  # noqa: F401
 
 
 def morton_order(bodies: np.ndarray, bits: int = 10) -> np.ndarray:
@@ -51,169 +51,195 @@ def morton_order(bodies: np.ndarray, bits: int = 10) -> np.ndarray:
     return np.argsort(key, kind="stable")
 
 
-class HipBackend:
-    """Force/integrate on the rank's GPU through libnbody_hip.so, with a compute stream (the
-    context's launch stream) and a communication stream for the all-gather."""
+def shard_plan(rank: int, world: int, n_total: int, schedule: int = SCHEDULE_SYMMETRIC) -> _lib.ShardPlan:
+    """nbody_shard_plan: what `rank` of `world` does for n_total bodies (no device needed)."""
+    p = _lib.ShardPlan()
+    rc = _lib.load().nbody_shard_plan(rank, world, n_total, schedule, C.byref(p))
+    if rc != _lib.OK:
+        raise _lib.NBodyError(rc, f"bad shard geometry: rank {rank} of {world}, {n_total} bodies, schedule {schedule}")
+    return p
 
-    def __init__(self, device: torch.device, dt: float, eps2: float, kernel: int = KERNEL_FAST, **kernel_opts):
-        from .engine import Context
-        self.device = device
-        torch.cuda.set_device(device)
-        self.compute = torch.cuda.Stream(device=device)
-        self.comm = torch.cuda.Stream(device=device)
-        self.ctx = Context(device=device.index, dt=dt, eps2=eps2, kernel=kernel, stream=self.compute, **kernel_opts)
-        self._integrated = torch.cuda.Event()
-        self._gathered = torch.cuda.Event()
-        # optional per-step communication timing (bench.py): events around the all-gather on the comm
-        # stream and after the own-block pass on the compute stream
-        self.comm_timing = False
-        self._comm_events = []   # (gather_start, gather_end, local_pass_end) per step
 
-    def empty(self, n: int) -> torch.Tensor:
-        return torch.zeros((n, 4), dtype=torch.float32, device=self.device)
+def schedule_of(kernel: int) -> int:
+    return {_lib.KERNEL_STRICT: SCHEDULE_CANONICAL, _lib.KERNEL_ONESIDED: SCHEDULE_ONESIDED}.get(kernel, SCHEDULE_SYMMETRIC)
 
-    def from_numpy(self, a: np.ndarray) -> torch.Tensor:
-        return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.device)
 
-    def accel_range(self, x, a_own, i0, i1, j0, j1, accumulate):
-        self.ctx.accel_range(x, a_own, i0, i1, j0, j1, accumulate)
+class TorchComm:
+    """The two collectives of the sharded step over torch.distributed, on torch tensors of bodies
+    ((n,4) float32, CPU or GPU). NCCL (= RCCL) works on device memory in place; with gloo, device
+    tensors are staged through the host (rehearsals on a box with fewer GPUs than ranks)."""
 
-    def accel_wrapped(self, x, a_own, i0, i1, j0, count, accumulate):
-        self.ctx.accel_wrapped(x, a_own, i0, i1, j0, count, accumulate)
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.nccl = dist.is_initialized() and dist.get_backend(group) == "nccl"
 
-    def integrate_range(self, x, v_own, a_own, i0, i1):
-        self.ctx.integrate_range(x, v_own, a_own, i0, i1)
+    def all_gather(self, x_full: torch.Tensor, shard: int) -> None:
+        own = x_full[self.rank * shard:(self.rank + 1) * shard]
+        if self.world == 1:
+            return
+        if self.nccl:
+            dist.all_gather_into_tensor(x_full, own, group=self.group)   # RCCL, in place
+            return
+        parts = [torch.empty((shard, 4), dtype=x_full.dtype) for _ in range(self.world)]
+        dist.all_gather(parts, own.detach().cpu().contiguous(), group=self.group)
+        x_full.copy_(torch.cat(parts))
 
-    # -- stream choreography ---------------------------------------------------------------
-    def all_gather(self, x_full: torch.Tensor, i0: int, i1: int, group) -> None:
-        """Start the in-place all-gather of the own block on the comm stream, after the
-        integrate that produced it."""
-        self.comm.wait_event(self._integrated)
-        with torch.cuda.stream(self.comm):
-            if self.comm_timing:
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
-                      torch.cuda.Event(enable_timing=True))
-                self._comm_events.append(ev)
-                ev[0].record(self.comm)
-            if dist.get_backend(group) == "nccl":
-                dist.all_gather_into_tensor(x_full, x_full[i0:i1], group=group)   # RCCL, in place
-            else:
-                # gloo (rehearsals on a box without one GPU per rank): stage through a list
-                world = dist.get_world_size(group)
-                parts = [torch.empty_like(x_full[i0:i1]) for _ in range(world)]
-                dist.all_gather(parts, x_full[i0:i1].clone(), group=group)
-                x_full.copy_(torch.cat(parts))
-            self._gathered.record(self.comm)
-            if self.comm_timing:
-                self._comm_events[-1][1].record(self.comm)
+    def exchange(self, sends, jbuf: torch.Tensor, recvs, rbuf: torch.Tensor) -> None:
+        """sends / recvs: sequences of (peer, offset, count); one grouped send/recv."""
+        if self.world == 1 or (not sends and not recvs):
+            return
+        if self.nccl:
+            ops = [dist.P2POp(dist.isend, jbuf[o:o + c], p, self.group) for (p, o, c) in sends]
+            ops += [dist.P2POp(dist.irecv, rbuf[o:o + c], p, self.group) for (p, o, c) in recvs]
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()          # orders the current stream behind the transfer; the host does not block
+            return
+        out = [jbuf[o:o + c].detach().cpu().contiguous() for (_, o, c) in sends]
+        inp = [torch.empty((c, 4), dtype=rbuf.dtype) for (_, _, c) in recvs]
+        reqs = [dist.isend(t, p, group=self.group) for t, (p, _, _) in zip(out, sends)]
+        reqs += [dist.irecv(t, p, group=self.group) for t, (p, _, _) in zip(inp, recvs)]
+        for r in reqs:
+            r.wait()
+        for t, (_, o, c) in zip(inp, recvs):
+            rbuf[o:o + c].copy_(t)
 
-    def wait_gather(self) -> None:
-        if self.comm_timing and self._comm_events:
-            self._comm_events[-1][2].record(self.compute)   # the own-block pass has been queued before this point
-        self.compute.wait_event(self._gathered)
 
-    def comm_report(self) -> dict:
-        """Mean all-gather time and the part of it NOT hidden behind the own-block force pass."""
-        self.sync()
-        if not self._comm_events:
-            return {"steps": 0}
-        gather = [a.elapsed_time(b) for a, b, _ in self._comm_events]
-        exposed = [max(0.0, c.elapsed_time(b)) for _, b, c in self._comm_events]   # local pass end -> gather end
-        self._comm_events = []
-        return {"steps": len(gather), "all_gather_ms_avg": sum(gather) / len(gather),
-                "exposed_ms_avg": sum(exposed) / len(exposed)}
+class _DeviceArray:
+    """Zero-copy view of device memory the library owns, for torch.as_tensor."""
 
-    def ready(self) -> None:
-        """Allocation/upload barrier: tensors were filled on torch's current stream, kernels run on
-        self.compute / self.comm, which do not synchronise with it implicitly."""
-        torch.cuda.synchronize(self.device)
-
-    def mark_integrated(self) -> None:
-        self._integrated.record(self.compute)
-
-    def sync(self) -> None:
-        self.compute.synchronize()
-        self.comm.synchronize()
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n, 4), "typestr": "<f4", "data": (ptr, False), "version": 3, "strides": None}
 
 
 class ShardedSimulation:
-    """`steps` x (all-gather, local forces, remote forces, integrate) over the ranks of `group`."""
+    """`steps` x (all-gather, own-block forces, cross/remote forces, exchange, integrate) over the ranks of `group`."""
 
     def __init__(self, bodies: np.ndarray, dt: float = _lib.DEFAULT_DT, eps2: float = _lib.DEFAULT_EPS2,
-                 group=None, backend=None, kernel: int = KERNEL_FAST, spatial_sort: bool = False, **kernel_opts):
+                 group=None, kernel: int = KERNEL_FAST, device: Optional[torch.device] = None, spatial_sort: bool = False,
+                 comm: Optional[TorchComm] = None, **kernel_opts):
+        from .engine import Context
         bodies = np.ascontiguousarray(bodies, np.float32)
         if bodies.ndim != 2 or bodies.shape[1] != 4:
             raise ValueError("bodies must be (n,4) float32 {x,y,z,mass}")
+        if not torch.cuda.is_available():
+            raise _lib.NBodyError(_lib.ERR_HIP, "no HIP device: the sharded step has no CPU path")
         # optional one-off Morton sort: index blocks become spatial blocks; undone in gather_state()
         self.perm = morton_order(bodies) if spatial_sort and len(bodies) else None
         if self.perm is not None:
             bodies = np.ascontiguousarray(bodies[self.perm])
-        self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.comm = comm if comm is not None else TorchComm(group)
+        self.group, self.world, self.rank = self.comm.group, self.comm.world, self.comm.rank
         self.n = bodies.shape[0]
-        self.shard = (self.n + self.world - 1) // self.world
-        self.n_pad = self.shard * self.world
-        self.i0 = self.rank * self.shard
-        self.i1 = self.i0 + self.shard
-        if backend is None:
-            if not torch.cuda.is_available():
-                raise _lib.NBodyError(_lib.ERR_HIP, "no HIP device: the sharded step has no CPU path")
-            local = self.rank % max(torch.cuda.device_count(), 1)
-            backend = HipBackend(torch.device("cuda", local), dt, eps2, kernel=kernel, **kernel_opts)
-        self.backend = backend
-        padded = np.zeros((self.n_pad, 4), np.float32)
-        padded[: self.n] = bodies
-        if self.n_pad > self.n and self.n > 0:
-            padded[self.n:, :3] = bodies[0, :3]  # massless, on top of body 0: contributes +-0
-        self.x = backend.from_numpy(padded)          # every rank starts from the same full array
-        self.v = backend.empty(self.shard)
-        self.a = backend.empty(self.shard)
-        self._fresh = True                           # X_full already consistent: skip first gather
-        # the uploads and zero fills above ran on the allocating stream: finish them before the first
-        # kernel on the backend's own (non-blocking) streams reads or overwrites those arrays
-        ready = getattr(backend, "ready", None)
-        if ready is not None:
-            ready()
-        backend.mark_integrated()
+        if device is None:
+            device = torch.device("cuda", self.rank % max(torch.cuda.device_count(), 1))
+        self.device = device
+        torch.cuda.set_device(device)
+        sym_waves, sym_bpl = kernel_opts.pop("sym_waves", 0), kernel_opts.pop("sym_bpl", 0)
+        self.ctx = Context(device=device.index, dt=dt, eps2=eps2, kernel=kernel, **kernel_opts)
+        if sym_waves or sym_bpl:
+            self.ctx.set_symmetric_shape(sym_waves, sym_bpl)
+        self._lib = _lib.load()
+        # the callbacks stay referenced for the life of the shard (ctypes does not keep them alive)
+        self._cb_gather = _lib.ALL_GATHER_FN(self._on_all_gather)
+        self._cb_exchange = _lib.EXCHANGE_FN(self._on_exchange)
+        self._comm_struct = _lib.Comm(None, self._cb_gather, self._cb_exchange)
+        self._h = C.c_void_p()
+        self._error = None
+        check(self._lib.nbody_shard_create(C.byref(self._h), self.ctx._h, self.rank, self.world, self.n, C.byref(self._comm_struct)))
+        self.plan = _lib.ShardPlan()
+        check(self._lib.nbody_shard_get_plan(self._h, C.byref(self.plan)))
+        self.shard, self.n_pad, self.i0, self.i1 = self.plan.shard, self.plan.n_pad, self.plan.i0, self.plan.i1
+        ptrs = [C.c_void_p() for _ in range(5)]
+        check(self._lib.nbody_shard_buffers(self._h, *[C.byref(p) for p in ptrs]))
+        wrap = lambda p, n: torch.as_tensor(_DeviceArray(p.value, max(n, 1)), device=device)[:n]
+        self.x = wrap(ptrs[0], self.n_pad)          # all positions (library-owned device memory)
+        self.v = wrap(ptrs[1], self.shard)
+        self.a = wrap(ptrs[2], self.shard)
+        self._jbuf = wrap(ptrs[3], self.plan.jbuf_bodies)
+        self._rbuf = wrap(ptrs[4], self.plan.rbuf_bodies)
+        check(self._lib.nbody_shard_upload(self._h, C.c_void_p(bodies.ctypes.data)))
+
+    # -- the two collectives, called by the library with the communication stream to enqueue on -----------
+    def _on_all_gather(self, user, d_x_full, bodies_per_rank, stream):
+        try:
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.device)):
+                self.comm.all_gather(self.x, bodies_per_rank)
+            return 0
+        except Exception as e:   # an exception must not unwind through the C frame
+            self._error = e
+            return 1
+
+    def _on_exchange(self, user, send, n_sends, d_jbuf, recv, n_recvs, d_rbuf, stream):
+        try:
+            sends = [(send[k].peer, send[k].offset, send[k].count) for k in range(n_sends)]
+            recvs = [(recv[k].peer, recv[k].offset, recv[k].count) for k in range(n_recvs)]
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.device)):
+                self.comm.exchange(sends, self._jbuf, recvs, self._rbuf)
+            return 0
+        except Exception as e:
+            self._error = e
+            return 1
+
+    def _check(self, rc: int) -> None:
+        if rc != _lib.OK and self._error is not None:
+            e, self._error = self._error, None
+            raise e
+        check(rc)
 
     def step(self, steps: int = 1) -> None:
-        b = self.backend
-        for _ in range(steps):
-            gather = self.world > 1 and not self._fresh
-            if gather:
-                b.all_gather(self.x, self.i0, self.i1, self.group)
-            b.accel_range(self.x, self.a, self.i0, self.i1, self.i0, self.i1, False)
-            if gather:
-                b.wait_gather()
-            if self.world > 1:
-                # every other rank's block in ONE launch: sources i1, i1+1, ... wrapping around to i0-1
-                b.accel_wrapped(self.x, self.a, self.i0, self.i1, self.i1 % self.n_pad, self.n_pad - self.shard, True)
-            b.integrate_range(self.x, self.v, self.a, self.i0, self.i1)
-            b.mark_integrated()
-            self._fresh = False
+        self._check(self._lib.nbody_shard_step(self._h, steps))
 
     def sync(self) -> None:
-        self.backend.sync()
+        self._check(self._lib.nbody_shard_sync(self._h))
+
+    def comm_timing(self, enable: bool) -> None:
+        self._check(self._lib.nbody_shard_comm_timing(self._h, 1 if enable else 0))
+
+    def comm_report(self) -> dict:
+        """Per-step means: all-gather time, the part of it not hidden behind the own-block pass, exchange time."""
+        k, g, ge, x = C.c_int(), C.c_double(), C.c_double(), C.c_double()
+        self._check(self._lib.nbody_shard_comm_report(self._h, C.byref(k), C.byref(g), C.byref(ge), C.byref(x)))
+        return {"steps": k.value, "all_gather_ms_avg": g.value, "exposed_ms_avg": ge.value, "exchange_ms_avg": x.value,
+                "schedule": {0: "canonical", 1: "onesided", 2: "symmetric"}[self.plan.schedule]}
+
+    def own_state(self):
+        """(x, v, a) of the own block (shard rows, padding included) as numpy arrays."""
+        out = [np.zeros((self.shard, 4), np.float32) for _ in range(3)]
+        self._check(self._lib.nbody_shard_download(self._h, *[C.c_void_p(o.ctypes.data) for o in out]))
+        return tuple(out)
 
     def gather_state(self):
         """(x, v, a) of all N bodies on every rank, as numpy arrays (test/diagnostic helper)."""
-        self.sync()
-        outs = []
+        own = self.own_state()
         if self.world > 1:
-            # bring X_full up to date first (the own block was advanced by the last integrate)
-            xs = [torch.empty_like(self.x[self.i0:self.i1]) for _ in range(self.world)]
-            dist.all_gather(xs, self.x[self.i0:self.i1].contiguous(), group=self.group)
-            outs.append(torch.cat(xs))
-            for t in (self.v, self.a):
+            outs = []
+            for o in own:
+                t = torch.from_numpy(o)
+                if self.comm.nccl:
+                    t = t.to(self.device)
                 parts = [torch.empty_like(t) for _ in range(self.world)]
-                dist.all_gather(parts, t.contiguous(), group=self.group)
-                outs.append(torch.cat(parts))
+                dist.all_gather(parts, t, group=self.group)
+                outs.append(torch.cat(parts).cpu().numpy())
         else:
-            outs = [self.x, self.v, self.a]
-        res = tuple(o.cpu().numpy()[: self.n] for o in outs)
+            outs = list(own)
+        res = tuple(o[: self.n] for o in outs)
         if self.perm is not None:       # back to the caller's body order
             inv = np.empty_like(self.perm)
             inv[self.perm] = np.arange(self.n)
             res = tuple(r[inv] for r in res)
         return res
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.nbody_shard_destroy(self._h)
+            self._h = C.c_void_p()
+            self.x = self.v = self.a = self._jbuf = self._rbuf = None
+            self.ctx.close()            # after the shard: it launches on the context's stream
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

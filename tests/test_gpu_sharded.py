@@ -34,72 +34,172 @@ def test_one_rank_nccl_group_equals_single_gpu(nb):
         sim = nb.engine.Simulation(x0, dt=0.01, eps2=0.002)
         sim.run(4)
         x, v, a = sim.state()
-        assert np.abs(xs - x)[:, :3].max() <= 1e-6
-        assert np.abs(as_ - a)[:, :3].max() / np.abs(a[:, :3]).max() <= 1e-5
+        assert np.array_equal(xs, x) and np.array_equal(vs, v) and np.array_equal(as_, a)   # one rank == nbody_step, bit for bit
         # the RCCL calls of the multi-rank path, as far as one rank can exercise them: the in-place
-        # all_gather_into_tensor on the communication stream, the event hand-over, MAX all-reduce, barrier
+        # all_gather_into_tensor on the library's communication stream, MAX all-reduce, barrier
         before = sh.x.clone()
-        sh.backend.all_gather(sh.x, sh.i0, sh.i1, None)
-        sh.backend.wait_gather()
-        sh.sync()
+        assert sh._on_all_gather(None, None, sh.shard, torch.cuda.current_stream().cuda_stream) == 0
+        dist.all_gather_into_tensor(sh.x, sh.x[sh.i0:sh.i1])
+        torch.cuda.synchronize()
         assert torch.equal(sh.x, before)
         t = torch.tensor([1.5], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.barrier()
         assert float(t.item()) == 1.5
-        sh.step(2)                       # and stepping still works after a gather
+        sh.step(2)                       # and stepping still works afterwards
         sh.sync()
+        sh.close()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("blocks,kernel", [(2, "strict"), (3, "strict"), (2, "fast"), (8, "fast")])
-def test_block_decomposition_on_one_device(nb, oracle, blocks, kernel):
-    """Each 'rank' = one context on the same GPU; the all-gather is a device copy. Strict kernel in
-    canonical block order is bit-identical to the single-device Jacobi oracle."""
-    n, steps, dt = 2040, 2, 0.1   # divisible by 2, 3 and 8
-    x0 = nb.engine.seeded_bodies(n, 0, 17)
-    k = nb.KERNEL_STRICT if kernel == "strict" else nb.KERNEL_FAST
-    S = n // blocks
-    ranks = []
-    for r in range(blocks):
-        ctx = nb.engine.Context(dt=dt, kernel=k)
-        ranks.append(dict(ctx=ctx, x=torch.from_numpy(x0).cuda(), v=torch.zeros((S, 4), device="cuda"),
-                          a=torch.zeros((S, 4), device="cuda"), i0=r * S, i1=(r + 1) * S))
-    for _ in range(steps):
-        for R in ranks:
-            c = R["ctx"]
-            if kernel == "strict":   # canonical order: the running sum continues block after block
-                c.accel_range(R["x"], R["a"], R["i0"], R["i1"], 0, n, False)
-            else:                    # the schedule of sharded.py: own block, then before, then after
-                c.accel_range(R["x"], R["a"], R["i0"], R["i1"], R["i0"], R["i1"], False)
-                if R["i0"] > 0:
-                    c.accel_range(R["x"], R["a"], R["i0"], R["i1"], 0, R["i0"], True)
-                if R["i1"] < n:
-                    c.accel_range(R["x"], R["a"], R["i0"], R["i1"], R["i1"], n, True)
-            c.integrate_range(R["x"], R["v"], R["a"], R["i0"], R["i1"])
-            c.sync()
-        # "all-gather": every rank receives every other rank's advanced block
-        for R in ranks:
-            for Q in ranks:
-                if Q is not R:
-                    R["x"][Q["i0"]:Q["i1"]] = Q["x"][Q["i0"]:Q["i1"]]
+class _OneThreadRanks:
+    """`world` ranks of the native sharded step (nbody_shard_*) driven by ONE host thread on one GPU: the step is
+    taken phase by phase (nbody_shard_step_phase) for all ranks, and the two collectives are plain device copies
+    made by the callbacks from what the plans say — exactly the transport contract of nbody_comm."""
+
+    def __init__(self, nb, x0, world, kernel, dt, eps2, sym_shape=None):
+        import ctypes as C
+        self.C, self.nb, self.lib, self.world = C, nb, nb.load(), world
+        L = nb._lib
+        self.ctxs, self.shards, self.plans, self.bufs, self._keep = [], [], [], [], []
+        for r in range(world):
+            ctx = nb.engine.Context(dt=dt, eps2=eps2, kernel=kernel)
+            if sym_shape:
+                ctx.set_symmetric_shape(*sym_shape)
+            g = L.ALL_GATHER_FN(lambda user, d_x, per_rank, stream, r=r: self._gather(r, per_rank))
+            e = L.EXCHANGE_FN(lambda user, send, ns, d_j, recv, nr, d_r, stream, r=r: self._exchange(r, send, ns, recv, nr))
+            comm = L.Comm(None, g, e)
+            h = C.c_void_p()
+            L.check(self.lib.nbody_shard_create(C.byref(h), ctx._h, r, world, len(x0), C.byref(comm)))
+            plan = L.ShardPlan()
+            L.check(self.lib.nbody_shard_get_plan(h, C.byref(plan)))
+            ptrs = [C.c_void_p() for _ in range(5)]
+            L.check(self.lib.nbody_shard_buffers(h, *[C.byref(p) for p in ptrs]))
+            wrap = lambda p, n: torch.as_tensor(nb.sharded._DeviceArray(p.value, max(n, 1)), device="cuda")[:n]
+            self.bufs.append(dict(x=wrap(ptrs[0], plan.n_pad), v=wrap(ptrs[1], plan.shard), a=wrap(ptrs[2], plan.shard),
+                                  j=wrap(ptrs[3], plan.jbuf_bodies), r=wrap(ptrs[4], plan.rbuf_bodies)))
+            L.check(self.lib.nbody_shard_upload(h, C.c_void_p(x0.ctypes.data)))
+            self.ctxs.append(ctx); self.shards.append(h); self.plans.append(plan); self._keep.append((g, e, comm))
+        self.gathers = self.exchanges = 0
+
+    def _gather(self, r, per_rank):
+        self.gathers += 1
+        for q in range(self.world):                 # every other rank's advanced block
+            if q != r:
+                self.bufs[r]["x"][q * per_rank:(q + 1) * per_rank] = self.bufs[q]["x"][q * per_rank:(q + 1) * per_rank]
+        return 0
+
+    def _exchange(self, r, send, ns, recv, nr):
+        self.exchanges += 1
+        for k in range(nr):                         # pull what each peer's plan says it sends to r
+            q, off, cnt = recv[k].peer, recv[k].offset, recv[k].count
+            pq = self.plans[q]
+            src = [pq.send[m] for m in range(pq.n_sends) if pq.send[m].peer == r]
+            assert len(src) == 1 and src[0].count == cnt and src[0].body0 == recv[k].body0
+            self.bufs[r]["r"][off:off + cnt] = self.bufs[q]["j"][src[0].offset:src[0].offset + cnt]
+        return 0
+
+    def step(self, steps):
+        for _ in range(steps):
+            for phase in range(4):
+                torch.cuda.synchronize()            # one thread plays every rank: finish a phase everywhere first
+                for h in self.shards:
+                    self.nb._lib.check(self.lib.nbody_shard_step_phase(h, phase))
         torch.cuda.synchronize()
+
+    def state(self, n):
+        S = self.plans[0].shard
+        x = torch.cat([self.bufs[r]["x"][r * S:(r + 1) * S] for r in range(self.world)]).cpu().numpy()[:n]
+        v = torch.cat([b["v"] for b in self.bufs]).cpu().numpy()[:n]
+        a = torch.cat([b["a"] for b in self.bufs]).cpu().numpy()[:n]
+        return x, v, a
+
+    def close(self):
+        for h in self.shards:
+            self.lib.nbody_shard_destroy(h)
+        self.bufs = []
+
+
+@pytest.mark.parametrize("world,kernel", [(2, "strict"), (3, "strict"), (8, "strict"), (2, "fast"), (3, "fast"), (4, "fast"),
+                                          (8, "fast"), (8, "onesided")])
+def test_callback_ranks_on_one_device(nb, oracle, world, kernel):
+    """The native step with several ranks on one device. STRICT: canonical order, bit-identical to the single-device
+    Jacobi oracle at every world size. FAST: the symmetric schedule (every pair once across the ranks, J-side sums
+    exchanged), ONESIDED: own block then everybody else — tolerance."""
+    n, steps, dt = 2037, 3, 0.1             # not divisible by 2, 3, 4 or 8: padding bodies take part
+    x0 = nb.engine.seeded_bodies(n, 0, 17)
+    k = {"strict": nb.KERNEL_STRICT, "fast": nb.KERNEL_SYMMETRIC, "onesided": nb.KERNEL_ONESIDED}[kernel]
+    ranks = _OneThreadRanks(nb, x0, world, k, dt, 0.002, sym_shape=(1, 2) if kernel == "fast" else None)
+    assert ranks.plans[0].schedule == {"strict": 0, "onesided": 1, "fast": 2}[kernel]
+    ranks.step(steps)
+    x, v, a = ranks.state(n)
+    assert ranks.gathers == world * (steps - 1)
+    assert ranks.exchanges == (world * steps if kernel == "fast" else 0)
     xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
     oracle.step_jacobi(xo, ao, vo, dt=dt, eps2=0.002, steps=steps)
-    xg = ranks[0]["x"].cpu().numpy()
-    ag = torch.cat([R["a"] for R in ranks]).cpu().numpy()
-    vg = torch.cat([R["v"] for R in ranks]).cpu().numpy()
     if kernel == "strict":
-        assert same_bits(xg, xo) and same_bits(vg, vo) and same_bits(ag, ao)
+        assert same_bits(x, xo) and same_bits(v, vo) and same_bits(a, ao)
     else:
-        assert np.abs(xg - xo)[:, :3].max() / 1e5 <= 1e-6
-        assert np.abs(ag - ao)[:, :3].max() / np.abs(ao[:, :3]).max() <= 1e-5
-    for R in ranks[1:]:
-        assert np.array_equal(R["x"].cpu().numpy(), xg)
+        assert np.abs(x - xo)[:, :3].max() / 1e5 <= 1e-6
+        assert np.abs(a - ao)[:, :3].max() / np.abs(ao[:, :3]).max() <= 1e-5
+    ranks.close()
 
 
-def _gloo_gpu_worker(rank, world, port, n, steps, q):
+def test_callback_ranks_symmetric_at_block_sizes_the_bench_uses(nb, oracle):
+    """4 ranks x 32768 bodies (the default block shapes: 2048-body blocks on both the own-block and the cross
+    launches): sampled targets against the CPU over all sources, momentum balance over the whole system."""
+    world, n = 4, 131072
+    x0 = nb.engine.seeded_bodies(n, 1, 99)
+    ranks = _OneThreadRanks(nb, x0, world, nb.KERNEL_FAST, 0.01, 0.002)
+    assert ranks.plans[0].schedule == 2 and ranks.ctxs[0].step_info(ranks.plans[0].shard)["symmetric"]
+    ranks.step(1)
+    x, v, a = ranks.state(n)
+    for i0 in (0, 70000, 131072 - 256):
+        truth = oracle.accel_range(x0, i0, i0 + 256, 0, n, eps2=0.002, f64acc=True)
+        assert np.abs(a[i0:i0 + 256] - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 1e-5
+    m = x0[:, 3:4].astype(np.float64)
+    assert np.abs((m * a[:, :3]).sum(0)).max() / (m * np.abs(a[:, :3])).sum() < 1e-6
+    ranks.close()
+
+
+def test_native_rccl_comm_with_one_rank(nb):
+    """nbody_comm_rccl_* (librccl loaded at run time, ncclCommInitRank / ncclAllGather / grouped send-recv) through
+    the C entry points, as far as a 1-GPU box allows: a world of one, bit-equal to nbody_step."""
+    import ctypes as C
+    lib, L = nb.load(), nb._lib
+    uid = (C.c_char * 128)()
+    L.check(lib.nbody_comm_rccl_unique_id(uid))
+    comm = L.Comm()
+    L.check(lib.nbody_comm_rccl_create(C.byref(comm), 0, 1, uid))
+    n = 20000                                   # >= 16384: the own-block pass is the symmetric kernel
+    x0 = nb.engine.seeded_bodies(n, 1, 5)
+    ctx = nb.engine.Context(dt=0.01, eps2=0.002)
+    h = C.c_void_p()
+    L.check(lib.nbody_shard_create(C.byref(h), ctx._h, 0, 1, n, C.byref(comm)))
+    L.check(lib.nbody_shard_upload(h, C.c_void_p(x0.ctypes.data)))
+    L.check(lib.nbody_shard_step(h, 3))
+    out = [np.zeros((n, 4), np.float32) for _ in range(3)]
+    L.check(lib.nbody_shard_download(h, *[C.c_void_p(o.ctypes.data) for o in out]))
+    # the collectives themselves, on the shard's own buffers (a world of one: both leave the data as it is)
+    ptrs = [C.c_void_p() for _ in range(5)]
+    L.check(lib.nbody_shard_buffers(h, *[C.byref(p) for p in ptrs]))
+    stream = torch.cuda.current_stream().cuda_stream
+    assert comm.all_gather(comm.user, ptrs[0], n, stream) == 0
+    assert comm.exchange(comm.user, None, 0, ptrs[3], None, 0, ptrs[4], stream) == 0
+    torch.cuda.synchronize()
+    out2 = [np.zeros((n, 4), np.float32) for _ in range(3)]
+    L.check(lib.nbody_shard_download(h, *[C.c_void_p(o.ctypes.data) for o in out2]))
+    assert all(np.array_equal(p, q) for p, q in zip(out, out2))
+    L.check(lib.nbody_shard_destroy(h))
+    L.check(lib.nbody_comm_rccl_destroy(C.byref(comm)))
+    sim = nb.engine.Simulation(x0, dt=0.01, eps2=0.002)
+    sim.run(3)
+    for got, want in zip(out, sim.state()):
+        assert np.array_equal(got, want)
+
+
+def _gloo_gpu_worker(rank, world, port, n, steps, kernel, q):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -108,25 +208,28 @@ def _gloo_gpu_worker(rank, world, port, n, steps, q):
     try:
         import nbody_amd
         x0 = nbody_amd.engine.seeded_bodies(n, 1, 77)
-        be = nbody_amd.sharded.HipBackend(torch.device("cuda", 0), 0.01, 0.002)   # every rank on the one GPU
-        sim = nbody_amd.sharded.ShardedSimulation(x0, dt=0.01, eps2=0.002, backend=be)
+        sim = nbody_amd.sharded.ShardedSimulation(x0, dt=0.01, eps2=0.002, kernel=kernel, device=torch.device("cuda", 0),
+                                                  sym_waves=1, sym_bpl=2)      # every rank on the one GPU
+        sim.comm_timing(True)
         sim.step(steps)
         x, v, a = sim.gather_state()
-        q.put((rank, x, v, a))
+        q.put((rank, x, v, a, sim.comm_report()))
+        sim.close()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n", [(2, 6000), (3, 5001)])
-def test_sharded_hip_backend_multi_rank_over_gloo(nb, oracle, world, n):
-    """The real HipBackend (streams, events, C-ABI calls, padding) with several ranks; the box has one
-    GPU, so all ranks share it and the collective goes over gloo instead of RCCL."""
+@pytest.mark.parametrize("world,n,kernel", [(2, 6000, 3), (3, 5001, 3), (4, 7000, 3), (2, 3000, 1)])
+def test_sharded_simulation_multi_rank_over_gloo(nb, oracle, world, n, kernel):
+    """The product path end to end (ShardedSimulation -> nbody_shard_* -> callbacks -> torch.distributed) with
+    several processes; the box has one GPU, so all ranks share it and the collectives go over gloo instead of RCCL.
+    kernel 3 = symmetric schedule with the exchange of J-side sums, 1 = strict (canonical order, bit-exact)."""
     import torch.multiprocessing as mp
     steps = 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gloo_gpu_worker, args=(r, world, port, n, steps, q)) for r in range(world)]
+    procs = [ctx.Process(target=_gloo_gpu_worker, args=(r, world, port, n, steps, kernel, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
@@ -136,10 +239,14 @@ def test_sharded_hip_backend_multi_rank_over_gloo(nb, oracle, world, n):
     x0 = nb.engine.seeded_bodies(n, 1, 77)
     xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
     oracle.step_jacobi(xo, ao, vo, dt=0.01, eps2=0.002, steps=steps)
-    for rank, x, v, a in res:
-        assert np.abs(x - xo)[:, :3].max() <= 1e-6
-        assert np.abs(a - ao)[:, :3].max() / np.abs(ao[:, :3]).max() <= 1e-5
+    for rank, x, v, a, rep in res:
+        if kernel == 1:
+            assert same_bits(x, xo) and same_bits(v, vo) and same_bits(a, ao)
+        else:
+            assert np.abs(x - xo)[:, :3].max() <= 1e-6
+            assert np.abs(a - ao)[:, :3].max() / np.abs(ao[:, :3]).max() <= 1e-5
         assert np.array_equal(x, res[0][1])
+        assert rep["steps"] == steps and rep["schedule"] == ("canonical" if kernel == 1 else "symmetric")
 
 
 def _run_bench(args, timeout=600):
