@@ -245,7 +245,8 @@ typedef struct nbody_comm {
 /* RCCL over xGMI from C, without a link-time dependency: librccl.so is loaded on first use. Rank 0 makes a unique
  * id (128 bytes), the caller distributes it to every rank by its own means, every rank creates its communicator. */
 int nbody_comm_rccl_unique_id(void* out_128_bytes);
-int nbody_comm_rccl_create(nbody_comm* out, int rank, int world, const void* unique_id_128_bytes);
+/* The communicator is created on `device` (< 0: the calling thread's current device). */
+int nbody_comm_rccl_create(nbody_comm* out, int rank, int world, const void* unique_id_128_bytes, int device);
 int nbody_comm_rccl_destroy(nbody_comm* comm);
 
 typedef struct nbody_shard nbody_shard;

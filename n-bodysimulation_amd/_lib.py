@@ -90,7 +90,7 @@ _SIGNATURES = {
     "nbody_ctx_get": (C.c_int, [_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_p)]),
     "nbody_shard_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(ShardPlan)]),
     "nbody_comm_rccl_unique_id": (C.c_int, [_p]),
-    "nbody_comm_rccl_create": (C.c_int, [C.POINTER(Comm), C.c_int, C.c_int, _p]),
+    "nbody_comm_rccl_create": (C.c_int, [C.POINTER(Comm), C.c_int, C.c_int, _p, C.c_int]),
     "nbody_comm_rccl_destroy": (C.c_int, [C.POINTER(Comm)]),
     "nbody_shard_create": (C.c_int, [C.POINTER(_p), _p, C.c_int, C.c_int, C.c_int, C.POINTER(Comm)]),
     "nbody_shard_destroy": (C.c_int, [_p]),

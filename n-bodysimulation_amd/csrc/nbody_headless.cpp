@@ -8,6 +8,9 @@
 //   simulationLoopNoVisual                          `steps` x simulate() (--sync-each-step) or one queued nbody_step (:142-160)
 //   (results discarded, no timing)                  D2H, --dump state, timing, one JSON line
 //   cudaFree / cudaFreeHost                         nbody_free_*                                   (:358-366)
+//   device 0 only (kernel.cu:630, main.cpp:287)     --ngpu G: G ranks in this process (one thread and one GPU each) over
+//                                                   nbody_shard_* + nbody_comm_rccl_* (RCCL all-gather / exchange)
+//   fp32 only                                       --precision f64: the build's double variant (nbody_step_f64, 1 GPU)
 //
 // State files (--dump P / --load P): P.json {n, steps_done, dt, eps2} + P.x.f4 / P.v.f4 / P.a.f4,
 // raw little-endian float4[N] — exactly the three arrays main.cpp owns (main.cpp:232-241).
@@ -18,6 +21,7 @@
 #include <iostream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "nbody.h"
@@ -54,7 +58,8 @@ static bool read_file(const std::string& path, void* p, size_t bytes)
 
 int main(int argc, char** argv)
 {
-    int n = N_BODIES, steps = 10, kernel = NBODY_KERNEL_FAST, sync_each = 0, interactive = 0, json = 1;
+    int n = N_BODIES, steps = 10, kernel = NBODY_KERNEL_FAST, sync_each = 0, interactive = 0, json = 1, ngpu = 1;
+    bool f64 = false, force_shard = false;
     long steps_done = 0;
     float dt = DT, eps2 = EPS2;
     unsigned long long seed = 12345;
@@ -68,14 +73,22 @@ int main(int argc, char** argv)
         else if (a == "--eps2") eps2 = (float)std::atof(val());
         else if (a == "--seed") seed = std::strtoull(val(), nullptr, 10);
         else if (a == "--init") init = val();            // libc (utils.cpp:30-37) | ref | plummer
-        else if (a == "--kernel") { std::string k = val(); kernel = (k == "strict" || k == "1") ? NBODY_KERNEL_STRICT : NBODY_KERNEL_FAST; }
+        else if (a == "--kernel") {
+            std::string k = val();
+            kernel = (k == "strict" || k == "1") ? NBODY_KERNEL_STRICT : k == "onesided" ? NBODY_KERNEL_ONESIDED
+                     : k == "symmetric" ? NBODY_KERNEL_SYMMETRIC : NBODY_KERNEL_FAST;
+        }
+        else if (a == "--ngpu") ngpu = std::atoi(val());
+        else if (a == "--shard") force_shard = true;     // run through nbody_shard_* + RCCL even with one GPU
+        else if (a == "--precision") { std::string q = val(); if (q != "f32" && q != "f64") die("--precision f32|f64"); f64 = q == "f64"; }
         else if (a == "--dump") dump = val();
         else if (a == "--load") load = val();
         else if (a == "--sync-each-step") sync_each = 1;
         else if (a == "--interactive") interactive = 1;
         else if (a == "--quiet") json = 0;
         else die("unknown option " + a + "\nusage: nbody_headless [--n N] [--steps K] [--dt f] [--eps2 f] [--init libc|ref|plummer] [--seed S]"
-                 " [--kernel fast|strict] [--dump P] [--load P] [--sync-each-step] [--interactive]");
+                 " [--kernel fast|strict|onesided|symmetric] [--ngpu G] [--shard] [--precision f32|f64] [--dump P] [--load P] [--sync-each-step]"
+                 " [--interactive]");
     }
     if (interactive) {
         // the reference's three prompts (main.cpp:163-228); only the headless all-pairs answers run here
@@ -91,6 +104,9 @@ int main(int argc, char** argv)
         steps = std::atoi(s.c_str());
     }
     if (n < 0 || steps < 0) die("n and steps must be >= 0");
+    if (ngpu < 1 || ngpu > NBODY_MAX_RANKS) die("--ngpu must be in [1, 64]");
+    if (f64 && (ngpu > 1 || sync_each || force_shard)) die("--precision f64 is a single-GPU variant stepped through nbody_step_f64");
+    if (ngpu > 1 && sync_each) die("--sync-each-step is the reference's single-device loop");
     const size_t bytes = sizeof(float4) * (size_t)n;
 
     float4 *bodies = nullptr, *velocity = nullptr, *accelerations = nullptr;
@@ -116,6 +132,93 @@ int main(int argc, char** argv)
         fill_with_zeroes4(accelerations, n);
     }
 
+    const char* kname = kernel == NBODY_KERNEL_STRICT ? "strict" : kernel == NBODY_KERNEL_ONESIDED ? "onesided"
+                        : kernel == NBODY_KERNEL_SYMMETRIC ? "symmetric" : "fast";
+    double secs = 0.0;
+    if (ngpu > 1 || force_shard) {
+        // G ranks in this process: one thread, one device, one context, one RCCL communicator and one shard each
+        int ndev = 0;
+        ok(nbody_device_count(&ndev));
+        if (ngpu > ndev) die("--ngpu " + std::to_string(ngpu) + " but only " + std::to_string(ndev) + " device(s) visible");
+        if (!load.empty()) die("--load resumes a single-device run (velocities are not redistributed)");
+        char uid[128];
+        ok(nbody_comm_rccl_unique_id(uid));
+        std::vector<std::string> errors(ngpu);
+        std::vector<double> rank_secs(ngpu, 0.0);
+        std::printf("Starting the simulation...\n");
+        auto rank_main = [&](int r) {
+            auto fail_here = [&](const char* what) { errors[r] = std::string(what) + ": " + nbody_last_error(); };
+            nbody_ctx* ctx = nullptr;
+            nbody_comm comm{};
+            nbody_shard* sh = nullptr;
+            if (nbody_ctx_create(&ctx, r) != NBODY_OK) return fail_here("nbody_ctx_create");
+            if (nbody_ctx_set_params(ctx, dt, eps2) != NBODY_OK || nbody_ctx_set_kernel(ctx, kernel, 0, 0, 0) != NBODY_OK) return fail_here("context setup");
+            if (nbody_comm_rccl_create(&comm, r, ngpu, uid, r) != NBODY_OK) return fail_here("nbody_comm_rccl_create");
+            if (nbody_shard_create(&sh, ctx, r, ngpu, n, &comm) != NBODY_OK) return fail_here("nbody_shard_create");
+            if (nbody_shard_upload(sh, (const nbody_float4*)bodies) != NBODY_OK) return fail_here("nbody_shard_upload");
+            const auto t0 = std::chrono::steady_clock::now();
+            if (nbody_shard_step(sh, steps) != NBODY_OK || nbody_shard_sync(sh) != NBODY_OK) return fail_here("nbody_shard_step");
+            rank_secs[r] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            nbody_shard_plan_t plan;
+            nbody_shard_get_plan(sh, &plan);
+            std::vector<nbody_float4> x(plan.shard), v(plan.shard), a(plan.shard);
+            if (nbody_shard_download(sh, x.data(), v.data(), a.data()) != NBODY_OK) return fail_here("nbody_shard_download");
+            for (int i = plan.i0; i < plan.i1 && i < n; ++i) {   // the own block back into the whole-system host arrays
+                std::memcpy(&bodies[i], &x[i - plan.i0], sizeof(float4));
+                std::memcpy(&velocity[i], &v[i - plan.i0], sizeof(float4));
+                std::memcpy(&accelerations[i], &a[i - plan.i0], sizeof(float4));
+            }
+            nbody_shard_destroy(sh);
+            nbody_comm_rccl_destroy(&comm);
+            nbody_ctx_destroy(ctx);
+        };
+        std::vector<std::thread> threads;
+        for (int r = 0; r < ngpu; ++r) threads.emplace_back(rank_main, r);
+        for (auto& t : threads) t.join();
+        for (int r = 0; r < ngpu; ++r) {
+            if (!errors[r].empty()) die("rank " + std::to_string(r) + ": " + errors[r]);
+            if (rank_secs[r] > secs) secs = rank_secs[r];
+        }
+        std::printf("Simulation complete\n");
+    } else if (f64) {
+        std::vector<nbody_double4> hx(n), hv(n), ha(n);
+        for (int i = 0; i < n; ++i) {
+            hx[i] = {bodies[i].x, bodies[i].y, bodies[i].z, bodies[i].w};
+            hv[i] = {velocity[i].x, velocity[i].y, velocity[i].z, 0.0};
+            ha[i] = {0.0, 0.0, 0.0, 0.0};
+        }
+        const size_t b8 = sizeof(nbody_double4) * (size_t)n;
+        void *dx = nullptr, *dv = nullptr, *da = nullptr;
+        ok(nbody_malloc_device(&dx, b8));
+        ok(nbody_malloc_device(&dv, b8));
+        ok(nbody_malloc_device(&da, b8));
+        ok(nbody_memcpy_h2d(dx, hx.data(), b8));
+        ok(nbody_memcpy_h2d(dv, hv.data(), b8));
+        ok(nbody_memcpy_h2d(da, ha.data(), b8));
+        nbody_ctx* ctx = nullptr;
+        ok(nbody_default_ctx(&ctx));
+        std::printf("Starting the simulation...\n");
+        const auto t0 = std::chrono::steady_clock::now();
+        ok(nbody_step_f64(ctx, (nbody_double4*)dx, (nbody_double4*)da, (nbody_double4*)dv, n, steps, (double)dt, (double)eps2));
+        ok(nbody_ctx_sync(ctx));
+        secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::printf("Simulation complete\n");
+        ok(nbody_memcpy_d2h(hx.data(), dx, b8));
+        ok(nbody_memcpy_d2h(hv.data(), dv, b8));
+        ok(nbody_memcpy_d2h(ha.data(), da, b8));
+        if (!dump.empty() && (!write_file(dump + ".x.f8", hx.data(), b8) || !write_file(dump + ".v.f8", hv.data(), b8) ||
+                              !write_file(dump + ".a.f8", ha.data(), b8)))
+            die("cannot write state " + dump);
+        for (int i = 0; i < n; ++i) {   // the fp32 view of the result (what the JSON line and the .f4 files carry)
+            bodies[i] = {(float)hx[i].x, (float)hx[i].y, (float)hx[i].z, (float)hx[i].w};
+            velocity[i] = {(float)hv[i].x, (float)hv[i].y, (float)hv[i].z, 0.0f};
+            accelerations[i] = {(float)ha[i].x, (float)ha[i].y, (float)ha[i].z, 0.0f};
+        }
+        ok(nbody_free_device(dx));
+        ok(nbody_free_device(dv));
+        ok(nbody_free_device(da));
+        kname = "f64";
+    } else {
     float4 *d_bodies = nullptr, *d_velocity = nullptr, *d_accelerations = nullptr;
     ok(nbody_malloc_device((void**)&d_velocity, bytes));
     ok(nbody_malloc_device((void**)&d_accelerations, bytes));
@@ -145,32 +248,34 @@ int main(int argc, char** argv)
         ok(nbody_step(ctx, (nbody_float4*)d_bodies, (nbody_float4*)d_accelerations, (nbody_float4*)d_velocity, n, steps));
         ok(nbody_ctx_sync(ctx));
     }
-    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::printf("Simulation complete\n");                // main.cpp:158
 
     ok(nbody_memcpy_d2h(bodies, d_bodies, bytes));
     ok(nbody_memcpy_d2h(velocity, d_velocity, bytes));
     ok(nbody_memcpy_d2h(accelerations, d_accelerations, bytes));
+    ok(nbody_free_device(d_bodies));
+    ok(nbody_free_device(d_velocity));
+    ok(nbody_free_device(d_accelerations));
+    }
     if (!dump.empty()) {
         if (!write_file(dump + ".x.f4", bodies, bytes) || !write_file(dump + ".v.f4", velocity, bytes) ||
             !write_file(dump + ".a.f4", accelerations, bytes))
             die("cannot write state " + dump);
         char hdr[256];
-        std::snprintf(hdr, sizeof hdr, "{\"n\": %d, \"steps_done\": %ld, \"dt\": %.9g, \"eps2\": %.9g, \"dtype\": \"f32\", \"layout\": \"float4 x,y,z,w LE\"}\n",
-                      n, steps_done + steps, dt, eps2);
+        std::snprintf(hdr, sizeof hdr, "{\"n\": %d, \"steps_done\": %ld, \"dt\": %.9g, \"eps2\": %.9g, \"dtype\": \"%s\", \"ngpu\": %d, "
+                      "\"layout\": \"float4 x,y,z,w LE (.f4)%s\"}\n",
+                      n, steps_done + steps, dt, eps2, f64 ? "f64" : "f32", ngpu, f64 ? "; double4 x,y,z,w LE (.f8)" : "");
         if (!write_file(dump + ".json", hdr, std::strlen(hdr))) die("cannot write " + dump + ".json");
     }
     if (json) {
         const double pairs = (double)n * (double)n * steps;
-        std::printf("{\"n\": %d, \"steps\": %d, \"dt\": %.9g, \"eps2\": %.9g, \"kernel\": \"%s\", \"seconds\": %.6f, \"pairs_per_s\": %.6g, "
+        std::printf("{\"n\": %d, \"steps\": %d, \"dt\": %.9g, \"eps2\": %.9g, \"kernel\": \"%s\", \"ngpu\": %d, \"seconds\": %.6f, \"pairs_per_s\": %.6g, "
                     "\"gflops_at_20\": %.6g, \"body0\": [%.9g, %.9g, %.9g, %.9g]}\n",
-                    n, steps, dt, eps2, kernel == NBODY_KERNEL_STRICT ? "strict" : "fast", secs, secs > 0 ? pairs / secs : 0.0,
+                    n, steps, dt, eps2, kname, ngpu, secs, secs > 0 ? pairs / secs : 0.0,
                     secs > 0 ? 20.0 * pairs / secs / 1e9 : 0.0, n ? bodies[0].x : 0.f, n ? bodies[0].y : 0.f, n ? bodies[0].z : 0.f,
                     n ? bodies[0].w : 0.f);
     }
-    ok(nbody_free_device(d_bodies));
-    ok(nbody_free_device(d_velocity));
-    ok(nbody_free_device(d_accelerations));
     ok(nbody_free_host(bodies));
     ok(nbody_free_host(velocity));
     ok(nbody_free_host(accelerations));

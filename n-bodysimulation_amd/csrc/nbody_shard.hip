@@ -471,7 +471,7 @@ int nbody_comm_rccl_unique_id(void* out_128_bytes)
     return NBODY_OK;
 }
 
-int nbody_comm_rccl_create(nbody_comm* out, int rank, int world, const void* unique_id_128_bytes)
+int nbody_comm_rccl_create(nbody_comm* out, int rank, int world, const void* unique_id_128_bytes, int device)
 {
     if (!out || !unique_id_128_bytes) return nbody_fail(NBODY_ERR_INVALID, "null argument");
     if (world < 1 || rank < 0 || rank >= world) return nbody_fail(NBODY_ERR_INVALID, "rank %d of %d", rank, world);
@@ -482,7 +482,16 @@ int nbody_comm_rccl_create(nbody_comm* out, int rank, int world, const void* uni
     u->world = world;
     RcclId id;
     std::memcpy(&id, unique_id_128_bytes, sizeof id);
-    const int rc = g_rccl.CommInitRank(&u->comm, world, id, rank);  // the communicator lives on the CURRENT device
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) {
+        delete u;
+        return nbody_fail(NBODY_ERR_HIP, "no current HIP device");
+    }
+    DeviceScope scope(device);  // the communicator lives on the device that is current during ncclCommInitRank
+    if (scope.err != hipSuccess) {
+        delete u;
+        return nbody_fail(NBODY_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.err));
+    }
+    const int rc = g_rccl.CommInitRank(&u->comm, world, id, rank);
     if (rc != 0) {
         delete u;
         return nbody_fail(NBODY_ERR_HIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(rc));

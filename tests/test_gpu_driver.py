@@ -77,6 +77,32 @@ def test_headless_strict_kernel_matches_oracle(oracle, nb, tmp_path):
     assert np.array_equal(_f4(tmp_path / "st.x.f4", n), xo) and np.array_equal(_f4(tmp_path / "st.v.f4", n), vo)
 
 
+def test_headless_sharded_path_over_rccl_and_f64(nb, oracle, tmp_path):
+    """--shard: the C++ host drives nbody_shard_* with the RCCL communicator (threads = ranks; one here, the box has
+    one GPU) and lands on the same bits as the plain run. --ngpu beyond the visible devices is refused.
+    --precision f64: nbody_step_f64 from the C++ host, checked against the all-double checker."""
+    import torch
+    n = 20000
+    base = ["--n", str(n), "--steps", "3", "--init", "plummer", "--dt", "0.01", "--seed", "4"]
+    _run([DRIVER, *base, "--quiet", "--dump", str(tmp_path / "plain")])
+    out = _run([DRIVER, *base, "--shard", "--dump", str(tmp_path / "shard")])
+    assert json.loads(out.strip().splitlines()[-1])["ngpu"] == 1
+    for ext in ("x", "v", "a"):
+        assert np.array_equal(_f4(tmp_path / f"plain.{ext}.f4", n), _f4(tmp_path / f"shard.{ext}.f4", n)), ext
+    r = subprocess.run([DRIVER, "--n", "4096", "--ngpu", str(torch.cuda.device_count() + 1)], capture_output=True, text=True)
+    assert r.returncode != 0 and "device(s) visible" in r.stderr
+    n = 1500
+    out = _run([DRIVER, "--n", str(n), "--steps", "3", "--init", "plummer", "--dt", "0.01", "--seed", "4", "--precision", "f64",
+                "--dump", str(tmp_path / "d")])
+    assert json.loads(out.strip().splitlines()[-1])["kernel"] == "f64"
+    x64 = np.fromfile(tmp_path / "d.x.f8", np.float64).reshape(n, 4)
+    xo = nb.engine.seeded_bodies(n, 1, 4).astype(np.float64)
+    vo, ao = np.zeros_like(xo), np.zeros_like(xo)
+    oracle.step_jacobi_f64(xo, ao, vo, dt=np.float32(0.01).item(), eps2=np.float32(0.002).item(), steps=3)
+    assert np.abs(x64 - xo)[:, :3].max() <= 1e-13
+    assert json.load(open(tmp_path / "d.json"))["dtype"] == "f64"
+
+
 def test_compare_host_to_device_program():
     """compareHostToDevice in the reference's own terms: lock-step GPU/CPU steps, then the 1 % rule on
     positions, velocities and accelerations."""

@@ -171,7 +171,7 @@ def test_native_rccl_comm_with_one_rank(nb):
     uid = (C.c_char * 128)()
     L.check(lib.nbody_comm_rccl_unique_id(uid))
     comm = L.Comm()
-    L.check(lib.nbody_comm_rccl_create(C.byref(comm), 0, 1, uid))
+    L.check(lib.nbody_comm_rccl_create(C.byref(comm), 0, 1, uid, -1))
     n = 20000                                   # >= 16384: the own-block pass is the symmetric kernel
     x0 = nb.engine.seeded_bodies(n, 1, 5)
     ctx = nb.engine.Context(dt=0.01, eps2=0.002)
