@@ -215,7 +215,9 @@ def main():
     if f64:
         class _F64Sim:   # same alloc/init/H2D sequence as engine.Simulation, double state
             def __init__(self):
-                self.ctx = nbody_amd.engine.Context(device=dev.index, jsplit=args.jsplit)
+                self.ctx = nbody_amd.engine.Context(device=dev.index, kernel=kernel, jsplit=args.jsplit)
+                if args.sym_waves or args.sym_bpl:
+                    self.ctx.set_symmetric_shape(args.sym_waves, args.sym_bpl)
                 self.x = torch.from_numpy(x0.astype(np.float64)).to(dev)
                 self.v = torch.zeros_like(self.x)
                 self.a = torch.zeros_like(self.x)
@@ -229,7 +231,16 @@ def main():
         ctx = sim.ctx
         run = lambda k: sim.run(k)
         sync = ctx.sync
-        info = {"symmetric": False, "slabs": args.jsplit or "auto", "kernel": "nbk::force_f64<2,512>", "evaluated_pairs": float(n) * n}
+        sym64 = kernel != nbody_amd.KERNEL_ONESIDED and (n >= 16384 or kernel == nbody_amd.KERNEL_SYMMETRIC)
+        info = {"symmetric": sym64, "slabs": args.jsplit or "auto", "evaluated_pairs": float(n) * n}
+        if sym64:   # the double-precision rotation kernel: blocks of 64*waves*bpl bodies, each unordered pair once
+            cands = [(4, 8), (2, 4), (1, 2)]
+            pick = next(((w, b) for (w, b) in cands if (not args.sym_waves or w == args.sym_waves) and (not args.sym_bpl or b == args.sym_bpl)
+                         and n >= 128 * 64 * w * b), cands[-1])
+            blk = 64 * pick[0] * pick[1]
+            nblk = -(-n // blk)
+            info.update({"block_bodies": blk, "slabs": nblk, "workgroups": nblk * (nblk + 1) // 2,
+                         "evaluated_pairs": float(nblk * (nblk + 1) // 2) * blk * blk})
     elif world == 1:
         sim = nbody_amd.engine.Simulation(x0, dt=args.dt, eps2=args.eps2, device=dev.index, **kopts)
         ctx = sim.ctx
@@ -364,7 +375,7 @@ def main():
             "frac": achieved / peak,
             "traffic": traffic,
             **({"traffic_note": traffic_note} if traffic_note else {}),
-            "kernel": "nbk::force_f64" if f64 else ("nbk::force_sym (fp32 packed, each unordered pair once)" if symmetric else "nbk::force_lds (fp32 packed, one-sided)"),
+            "kernel": ("nbk::force_sym<SymF64> (fp64, each unordered pair once)" if symmetric else "nbk::force_f64 (one-sided)") if f64 else ("nbk::force_sym (fp32 packed, each unordered pair once)" if symmetric else "nbk::force_lds (fp32 packed, one-sided)"),
             "kernel_ms_per_step": kernel_s_step * 1e3,
             "kernel_launches_per_step": launches_per_step,
             "kernel_launches": kernel_launches,

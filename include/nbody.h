@@ -119,7 +119,7 @@ int nbody_ctx_set_kernel(nbody_ctx* ctx, int kernel, int tile, int bodies_per_la
 
 /* Shape of the symmetric kernel: wave64s per workgroup and stationary bodies per lane; a block is
  * 64*waves*bodies_per_lane bodies. Built: (4,8) (2,8) (2,4) (1,4) (1,2); 0 = auto (the largest block that
- * still gives 64 blocks). */
+ * still gives 128 blocks). */
 int nbody_ctx_set_symmetric_shape(nbody_ctx* ctx, int waves, int bodies_per_lane);
 
 /* Launch on this HIP stream (a hipStream_t passed as void*; NULL = the context's own stream). */

@@ -209,8 +209,10 @@ bool sym_resolve(const nbody_ctx* c, int n, SymShape* out)
     for (int k = 0; k < kSymCands; ++k) {
         if ((c->sym_waves && kSymCand[k][0] != c->sym_waves) || (c->sym_bpl && kSymCand[k][1] != c->sym_bpl)) continue;
         pick = k;
-        // enough block pairs to keep every CU busy through the tail: nb >= 64 gives 2080 tasks
-        if ((long)n >= 64L * 64 * kSymCand[k][0] * kSymCand[k][1]) break;
+        // the largest block that still gives 128 blocks (8256 tasks): measured best at every size from 16384 to
+        // 262144 bodies (tools/smalln_probe.py, profiles/r02_smalln_probe_a.jsonl) — with 64 blocks the 2080 tasks
+        // fall 2 or 3 to a SIMD and the 3s set the kernel time
+        if ((long)n >= 128L * 64 * kSymCand[k][0] * kSymCand[k][1]) break;
     }
     if (pick < 0) return false;
     SymShape y{};
@@ -508,8 +510,8 @@ int nbody_ctx_set_symmetric_shape(nbody_ctx* c, int waves, int bodies_per_lane)
     for (int k = 0; k < kSymCands && !ok; ++k)
         ok = (waves == 0 || waves == kSymCand[k][0]) && (bodies_per_lane == 0 || bodies_per_lane == kSymCand[k][1]);
     if (!ok)
-        return fail(NBODY_ERR_CONFIG, "symmetric kernel is built for (waves, bodies_per_lane) in {(4,8),(2,8),(2,4),(1,4),(1,2)}; got (%d,%d)",
-                    waves, bodies_per_lane);
+        return fail(NBODY_ERR_CONFIG, "symmetric kernel is built for (waves, bodies_per_lane) in {(4,8),(2,8),(2,4),(1,4),(1,2)} "
+                    "(fp64: (4,8),(2,4),(1,2) of these); got (%d,%d)", waves, bodies_per_lane);
     c->sym_waves = waves;
     c->sym_bpl = bodies_per_lane;
     return NBODY_OK;
@@ -986,6 +988,54 @@ int nbody_step_f64(nbody_ctx* c, nbody_double4* d_bodies, nbody_double4* d_accel
     if (!(eps2 > 0.0)) return fail(NBODY_ERR_INVALID, "eps2 must be > 0");
     if (n == 0 || steps == 0) return NBODY_OK;
     ON_DEVICE(c);
+    nbk::IntegrateParamsF64 q{};
+    q.x = reinterpret_cast<double4*>(d_bodies);
+    q.v = reinterpret_cast<double4*>(d_velocity);
+    q.a = reinterpret_cast<double4*>(d_accelerations);
+    q.n = n;
+    q.dt = dt;
+    // the symmetric rotation kernel in double (FAST from 16384 bodies, or SYMMETRIC): shapes (waves, bodies per lane)
+    static const int cand[][2] = {{4, 8}, {2, 4}, {1, 2}};
+    if (c->kernel == NBODY_KERNEL_SYMMETRIC || (c->kernel == NBODY_KERNEL_FAST && n >= kSymMinAuto)) {
+        int pick = -1;
+        for (int k = 0; k < 3; ++k) {
+            if ((c->sym_waves && cand[k][0] != c->sym_waves) || (c->sym_bpl && cand[k][1] != c->sym_bpl)) continue;
+            pick = k;
+            if ((long)n >= 128L * 64 * cand[k][0] * cand[k][1]) break;
+        }
+        if (pick >= 0) {
+            const int W = cand[pick][0], BPL = cand[pick][1], B = 64 * W * BPL;
+            const int nb = (n + B - 1) / B;
+            if (nb >= 2 && nb <= kSymMaxSlabs) {
+                if (int rc = ensure_slabs(c, (size_t)nb * n * sizeof(double4))) return rc;
+                nbk::SymParamsF64 sp{};
+                sp.x = reinterpret_cast<const double4*>(d_bodies);
+                sp.slabs_i = static_cast<double4*>(c->slabs);
+                sp.slabs_j = sp.slabs_i;
+                sp.ni = n; sp.nj = n; sp.i0 = 0; sp.j0 = 0; sp.wrap = 0;
+                sp.nbi = nb; sp.nbj = nb; sp.stride_i = n; sp.stride_j = n; sp.rect = 0;
+                sp.eps2 = eps2;
+                q.slabs = static_cast<const double4*>(c->slabs);
+                q.nslab = nb;
+                q.slab_stride = n;
+                const int grid = nb * (nb - 1) / 2 + nb;
+                for (int k = 0; k < steps; ++k) {
+                    if (int rc = time_mark(c)) return rc;
+                    switch (W * 100 + BPL) {
+                        case 408: nbk::force_sym<nbk::SymF64<8>, 4><<<grid, 256, 0, c->stream>>>(sp); break;
+                        case 204: nbk::force_sym<nbk::SymF64<4>, 2><<<grid, 128, 0, c->stream>>>(sp); break;
+                        default: nbk::force_sym<nbk::SymF64<2>, 1><<<grid, 64, 0, c->stream>>>(sp); break;
+                    }
+                    HIP_TRY(hipGetLastError());
+                    if (int rc = time_mark(c)) return rc;
+                    nbk::integrate_f64<<<(n + nbk::kWG - 1) / nbk::kWG, nbk::kWG, 0, c->stream>>>(q);
+                    HIP_TRY(hipGetLastError());
+                }
+                return NBODY_OK;
+            }
+        }
+    }
+    // one-sided LDS-tiled kernel
     constexpr int BPL = 2, TILE = 512;
     const int blocks_x = (n + nbk::kWG * BPL - 1) / (nbk::kWG * BPL);
     int js = c->jsplit;
@@ -1002,15 +1052,9 @@ int nbody_step_f64(nbody_ctx* c, nbody_double4* d_bodies, nbody_double4* d_accel
     p.n = n;
     p.slab_stride = n;
     p.eps2 = eps2;
-    nbk::IntegrateParamsF64 q{};
-    q.x = reinterpret_cast<double4*>(d_bodies);
-    q.v = reinterpret_cast<double4*>(d_velocity);
-    q.a = reinterpret_cast<double4*>(d_accelerations);
     q.slabs = static_cast<const double4*>(c->slabs);
     q.nslab = js;
     q.slab_stride = n;
-    q.n = n;
-    q.dt = dt;
     for (int k = 0; k < steps; ++k) {
         if (int rc = time_mark(c)) return rc;
         nbk::force_f64<BPL, TILE><<<dim3(blocks_x, js), nbk::kWG, 0, c->stream>>>(p);

@@ -301,10 +301,11 @@ __global__ void __launch_bounds__(kWG, MINW) force_sgpr(const ForceParams p)
 // slab element is written exactly once per launch and the integrate kernel adds the nb slabs in
 // index order: deterministic, no float atomics.
 
-struct SymParams {
-    const float4* x;      // bodies {x,y,z,mass}, indexed absolutely
-    float4* slabs_i;      // I-side partial sums: slab s at slabs_i + s*stride_i, element = index within the I range
-    float4* slabs_j;      // J-side partial sums: slab s at slabs_j + s*stride_j, element = index within the J run
+template <class V4, class S>
+struct SymParamsT {
+    const V4* x;          // bodies {x,y,z,mass}, indexed absolutely
+    V4* slabs_i;          // I-side partial sums: slab s at slabs_i + s*stride_i, element = index within the I range
+    V4* slabs_j;          // J-side partial sums: slab s at slabs_j + s*stride_j, element = index within the J run
     int ni, nj;           // bodies of the I range / of the J run
     int i0, j0;           // absolute index of the first I / first J body
     int wrap;             // 0, or the array length: a J index at or beyond it continues at body 0
@@ -313,8 +314,10 @@ struct SymParams {
     int rect;             // 0: ONE range (I range == J run): block pairs I < J once + the diagonal blocks one-sided
                           //    (nbi == nbj == nb, slabs_i == slabs_j: slab J gets the I-side sums, slab I the J-side sums)
                           // 1: TWO disjoint ranges: every (I, J) block pair, symmetric; slab J of slabs_i, slab I of slabs_j
-    float eps2;
+    S eps2;
 };
+using SymParams = SymParamsT<float4, float>;
+using SymParamsF64 = SymParamsT<double4, double>;
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(const float v)
@@ -329,10 +332,28 @@ __device__ __forceinline__ float ror(const float v)
     else return dpp_mov<0x120 + S>(v);
 }
 
+template <int S>
+__device__ __forceinline__ double ror(const double v)
+{
+    if constexpr (S == 0) return v;
+    else {
+        const long long b = __builtin_bit_cast(long long, v);
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x120 + S, 0xf, 0xf, true);
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x120 + S, 0xf, 0xf, true);
+        return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+    }
+}
+
+template <class V4> __device__ __forceinline__ V4 zero4();
+template <> __device__ __forceinline__ float4 zero4<float4>() { return make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+template <> __device__ __forceinline__ double4 zero4<double4>() { return make_double4(0.0, 0.0, 0.0, 0.0); }
+
 // Packed arithmetic for the rotation kernel: BPL stationary bodies per lane, two per register pair.
 template <int BPL_>
 struct SymPacked {
     static_assert(BPL_ % 2 == 0, "packed maths handles bodies two at a time");
+    using S = float;
+    using V4 = float4;
     static constexpr int BPL = BPL_;
     static constexpr int H = BPL / 2;
     f32x2 x[H], y[H], z[H], m[H];
@@ -403,6 +424,8 @@ struct SymPacked {
 // Scalar arithmetic for the rotation kernel: the row rotation can fold into v_sub_f32_dpp / v_mul_f32_dpp.
 template <int BPL_>
 struct SymScalar {
+    using S = float;
+    using V4 = float4;
     static constexpr int BPL = BPL_;
     float x[BPL], y[BPL], z[BPL], m[BPL];
     float ax[BPL], ay[BPL], az[BPL];
@@ -451,10 +474,61 @@ struct SymScalar {
     }
 };
 
+// Double-precision arithmetic for the rotation kernel (the build's own fp64 variant, BASELINE configs[4]).
+// d^(-3/2): v_rsq_f64 seed (about 5e-8 relative, tools/rsq64_probe.hip) and ONE third-order step
+// y <- y (1 + r/2 + 3 r^2/8), r = 1 - d y^2 (error 5/16 r^3 ~ 1e-22): 5 ops, against 7 for two Newton steps.
+template <int BPL_>
+struct SymF64 {
+    using S = double;
+    using V4 = double4;
+    static constexpr int BPL = BPL_;
+    double x[BPL], y[BPL], z[BPL], m[BPL];
+    double ax[BPL], ay[BPL], az[BPL];
+    double e2;
+
+    __device__ __forceinline__ void set_eps2(const double eps2) { e2 = eps2; }
+    __device__ __forceinline__ void set(int k, const double4 b)
+    {
+        x[k] = b.x; y[k] = b.y; z[k] = b.z; m[k] = b.w;
+        ax[k] = 0.0; ay[k] = 0.0; az[k] = 0.0;
+    }
+    __device__ __forceinline__ double4 acc(int k) const { return make_double4(ax[k], ay[k], az[k], 0.0); }
+    template <bool SYM>
+    __device__ __forceinline__ void pairs(const double sx, const double sy, const double sz, const double sm, double& tx,
+                                          double& ty, double& tz)
+    {
+        tx = 0.0; ty = 0.0; tz = 0.0;
+        double rx[BPL], ry[BPL], rz[BPL], w[BPL];
+#pragma unroll
+        for (int k = 0; k < BPL; ++k) { rx[k] = sx - x[k]; ry[k] = sy - y[k]; rz[k] = sz - z[k]; }
+#pragma unroll
+        for (int k = 0; k < BPL; ++k) {
+            const double d = __builtin_fma(rz[k], rz[k], __builtin_fma(ry[k], ry[k], __builtin_fma(rx[k], rx[k], e2)));
+            double q = __builtin_amdgcn_rsq(d);
+            const double r = __builtin_fma(-d, q * q, 1.0);
+            q = __builtin_fma(q * r, __builtin_fma(0.375, r, 0.5), q);
+            w[k] = q * q * q;
+        }
+#pragma unroll
+        for (int k = 0; k < BPL; ++k) {
+            const double fi = sm * w[k];
+            ax[k] = __builtin_fma(rx[k], fi, ax[k]);
+            ay[k] = __builtin_fma(ry[k], fi, ay[k]);
+            az[k] = __builtin_fma(rz[k], fi, az[k]);
+            if (SYM) {
+                const double fj = m[k] * w[k];
+                tx = __builtin_fma(rx[k], fj, tx);
+                ty = __builtin_fma(ry[k], fj, ty);
+                tz = __builtin_fma(rz[k], fj, tz);
+            }
+        }
+    }
+};
+
 template <int S, bool SYM, class M>
-__device__ __forceinline__ void sym_step(M& t, const float4& bj, float4& aj)
+__device__ __forceinline__ void sym_step(M& t, const typename M::V4& bj, typename M::V4& aj)
 {
-    float tx, ty, tz;
+    typename M::S tx, ty, tz;
     t.template pairs<SYM>(ror<S>(bj.x), ror<S>(bj.y), ror<S>(bj.z), ror<S>(bj.w), tx, ty, tz);
     if (SYM) {  // a_j = -sum_i (m_i w) r, delivered to the moving body's lane
         aj.x -= ror<(16 - S) % 16>(tx);
@@ -464,7 +538,7 @@ __device__ __forceinline__ void sym_step(M& t, const float4& bj, float4& aj)
 }
 
 template <bool SYM, class M>
-__device__ __forceinline__ void sym_row_pass(M& t, const float4& bj, float4& aj)
+__device__ __forceinline__ void sym_row_pass(M& t, const typename M::V4& bj, typename M::V4& aj)
 {
     sym_step<0, SYM>(t, bj, aj);  sym_step<1, SYM>(t, bj, aj);  sym_step<2, SYM>(t, bj, aj);  sym_step<3, SYM>(t, bj, aj);
     sym_step<4, SYM>(t, bj, aj);  sym_step<5, SYM>(t, bj, aj);  sym_step<6, SYM>(t, bj, aj);  sym_step<7, SYM>(t, bj, aj);
@@ -476,6 +550,13 @@ __device__ __forceinline__ float next_row(const float v, const int addr)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
 }
+__device__ __forceinline__ double next_row(const double v, const int addr)
+{
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, (int)b);
+    const int hi = __builtin_amdgcn_ds_bpermute(addr, (int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
 
 // first index of row I in the row-major list of block pairs (I < J): I*(2nb - I - 1)/2
 __device__ __forceinline__ int sym_row_offset(int I, int nb) { return (int)(((long)I * (2L * nb - I - 1)) / 2); }
@@ -483,12 +564,13 @@ __device__ __forceinline__ int sym_row_offset(int I, int nb) { return (int)(((lo
 // block = 64*W threads. rect == 0: grid = nb*(nb-1)/2 pair tasks followed by nb diagonal tasks;
 // rect == 1: grid = nbi*nbj pair tasks.
 template <class M, int W, int MINW = 1>
-__global__ void __launch_bounds__(64 * W, MINW) force_sym(const SymParams p)
+__global__ void __launch_bounds__(64 * W, MINW) force_sym(const SymParamsT<typename M::V4, typename M::S> p)
 {
     constexpr int BPL = M::BPL;
     constexpr int B = 64 * W * BPL;
     constexpr int NCH = B / 64;
-    __shared__ float4 sh[B];
+    using V4 = typename M::V4;
+    __shared__ V4 sh[B];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -523,7 +605,7 @@ __global__ void __launch_bounds__(64 * W, MINW) force_sym(const SymParams p)
 #pragma unroll
     for (int k = 0; k < BPL; ++k) {
         const int i = ibase + k * 64;
-        t.set(k, i < p.ni ? p.x[p.i0 + i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        t.set(k, i < p.ni ? p.x[p.i0 + i] : zero4<V4>());
     }
     const int jbase = J * B + lane;  // index within the J run
     const int rot = ((lane + 16) & 63) << 2;
@@ -532,28 +614,28 @@ __global__ void __launch_bounds__(64 * W, MINW) force_sym(const SymParams p)
         const int j = jbase + c * 64;
         int ja = p.j0 + j;
         if (p.wrap && ja >= p.wrap) ja -= p.wrap;
-        return j < p.nj ? p.x[ja] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        return j < p.nj ? p.x[ja] : zero4<V4>();
     };
 
     if (!diag) {
 #pragma unroll
-        for (int e = tid; e < B; e += 64 * W) sh[e] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int e = tid; e < B; e += 64 * W) sh[e] = zero4<V4>();
         __syncthreads();
     }
     int c = w * BPL;  // chunk of this wave in round 0 (distinct per wave, NCH = W*BPL chunks)
-    float4 nxt = fetch(c);
+    V4 nxt = fetch(c);
     for (int q = 0; q < NCH; ++q) {
-        float4 bj = nxt;
+        V4 bj = nxt;
         const int cn = (c + 1 == NCH) ? 0 : c + 1;
         if (q + 1 < NCH) nxt = fetch(cn);
         if (diag) {
-            float4 aj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            V4 aj = zero4<V4>();
             for (int ph = 0; ph < 4; ++ph) {
                 sym_row_pass<false>(t, bj, aj);
                 bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot); bj.w = next_row(bj.w, rot);
             }
         } else {
-            float4 aj = sh[c * 64 + lane];
+            V4 aj = sh[c * 64 + lane];
             for (int ph = 0; ph < 4; ++ph) {
                 sym_row_pass<true>(t, bj, aj);
                 bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot); bj.w = next_row(bj.w, rot);
@@ -565,19 +647,19 @@ __global__ void __launch_bounds__(64 * W, MINW) force_sym(const SymParams p)
         c = cn;
     }
 
-    float4* const out_i = p.slabs_i + (size_t)J * p.stride_i;
+    V4* const out_i = p.slabs_i + (size_t)J * p.stride_i;
 #pragma unroll
     for (int k = 0; k < BPL; ++k) {
         const int i = ibase + k * 64;
         if (i < p.ni) out_i[i] = t.acc(k);
     }
     if (!diag) {
-        float4* const out_j = p.slabs_j + (size_t)I * p.stride_j;
+        V4* const out_j = p.slabs_j + (size_t)I * p.stride_j;
         for (int e = tid; e < B; e += 64 * W) {
             const int j = J * B + e;
             if (j < p.nj) {
-                float4 a = sh[e];
-                a.w = 0.0f;
+                V4 a = sh[e];
+                a.w = 0;
                 out_j[j] = a;
             }
         }
@@ -842,6 +924,7 @@ __global__ void __launch_bounds__(kWG) integrate_f64(const IntegrateParamsF64 p)
     const int i = blockIdx.x * kWG + threadIdx.x;
     if (i >= p.n) return;
     double4 a = p.slabs[i];
+#pragma unroll 8
     for (int s = 1; s < p.nslab; ++s) {
         const double4 q = p.slabs[(size_t)s * p.slab_stride + i];
         a.x += q.x; a.y += q.y; a.z += q.z;

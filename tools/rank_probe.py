@@ -1,27 +1,51 @@
-"""Developer probe: the per-step work of ONE rank of the weak-scaled sharded run (no communication),
-to predict scaling efficiency from a single GPU. usage: rank_probe.py G [G ...]"""
-import sys, os, time, json, math
+"""Developer probe: the per-step work of ONE rank of the sharded run, timed alone on one GPU with no-op collectives
+(nothing is exchanged, so the numbers are meaningless as physics — only the launch sequence and its time are real).
+Predicts the compute side of multi-GPU scaling from a single GPU.
+usage: rank_probe.py [--bodies N] [--kernel fast|onesided] G [G ...]"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-import nbody_amd
-def weak_n(g):
-    q = 8192 * g
-    return 262144 if g == 1 else int(round(262144 * math.sqrt(g) / q)) * q
-for G in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
-    n = weak_n(G); S = n // G
-    x = torch.from_numpy(nbody_amd.engine.seeded_bodies(n, 1, 1)).cuda()
-    v = torch.zeros((S, 4), device="cuda"); a = torch.zeros((S, 4), device="cuda")
-    ctx = nbody_amd.engine.Context(dt=0.01); ctx.reserve(S)
-    r = G // 2; i0, i1 = r * S, (r + 1) * S
-    def step():
-        ctx.accel_range(x, a, i0, i1, i0, i1, False)
-        if G > 1:
-            ctx.accel_wrapped(x, a, i0, i1, i1 % n, n - S, True)
-        ctx.integrate_range(x, v, a, i0, i1)
-    for _ in range(3): step()
-    ctx.sync(); t = time.perf_counter()
-    K = 10
-    for _ in range(K): step()
-    ctx.sync(); dt = (time.perf_counter() - t) / K
-    print(json.dumps({"G": G, "n": n, "shard": S, "ms_per_step": round(dt * 1e3, 3), "rank_pairs_per_s": float("%.4g" % (S * n / dt)),
-                      "job_pairs_per_s_if_all_ranks_equal": float("%.4g" % (n * n / dt))}))
+import torch  # noqa: E402
+import nbody_amd  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--bodies", type=int, default=1048576)
+ap.add_argument("--kernel", default="fast")
+ap.add_argument("--steps", type=int, default=6)
+ap.add_argument("worlds", type=int, nargs="*", default=[1, 2, 4, 8])
+args = ap.parse_args()
+L, lib = nbody_amd._lib, nbody_amd.load()
+x0 = nbody_amd.engine.seeded_bodies(args.bodies, 1, 1)
+kernel = {"fast": nbody_amd.KERNEL_FAST, "onesided": nbody_amd.KERNEL_ONESIDED}[args.kernel]
+for G in args.worlds:
+    rank = G // 2
+    ctx = nbody_amd.engine.Context(dt=0.01, kernel=kernel)
+    g = L.ALL_GATHER_FN(lambda *a: 0)
+    e = L.EXCHANGE_FN(lambda *a: 0)
+    comm = L.Comm(None, g, e)
+    h = C.c_void_p()
+    L.check(lib.nbody_shard_create(C.byref(h), ctx._h, rank, G, args.bodies, C.byref(comm)))
+    L.check(lib.nbody_shard_upload(h, C.c_void_p(x0.ctypes.data)))
+    plan = L.ShardPlan()
+    L.check(lib.nbody_shard_get_plan(h, C.byref(plan)))
+    L.check(lib.nbody_shard_step(h, 2))
+    L.check(lib.nbody_shard_sync(h))
+    ctx.timing(True)
+    t = time.perf_counter()
+    L.check(lib.nbody_shard_step(h, args.steps))
+    L.check(lib.nbody_shard_sync(h))
+    dt = (time.perf_counter() - t) / args.steps
+    force_ms, launches = ctx.timing_read()
+    n = args.bodies
+    print(json.dumps({"G": G, "rank": rank, "n": n, "shard": plan.shard, "schedule": plan.schedule,
+                      "ms_per_step": round(dt * 1e3, 3), "force_ms_per_step": round(force_ms / args.steps, 3),
+                      "force_launches_per_step": launches // args.steps,
+                      "rank_interactions_per_s": float("%.4g" % (plan.shard * float(plan.n_pad) / dt)),
+                      "job_pairs_per_s_if_all_ranks_equal": float("%.4g" % (float(n) * n / dt))}), flush=True)
+    L.check(lib.nbody_shard_destroy(h))
+    ctx.close()
