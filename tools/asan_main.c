@@ -18,6 +18,17 @@ int main(void) {
         nbody_fill_with_random4((nbody_float4*)X, n); nbody_fill_with_zeroes4((nbody_float4*)X, n); oracle_fill_with_random4(X, n); oracle_fill_with_zeroes4(X, n);
         (void)b; free(X); free(V); free(A); free(Xd); free(Vd); free(Ad);
     }
+    /* the shard plan (pure host logic of the multi-GPU step): every world size, every rank, the three schedules */
+    for (int world = 1; world <= NBODY_MAX_RANKS; ++world)
+        for (int rank = 0; rank < world; ++rank)
+            for (int sched = 0; sched < 3; ++sched) {
+                nbody_shard_plan_t p;
+                if (nbody_shard_plan(rank, world, 1000 + 37 * world, sched, &p) != NBODY_OK) { puts("plan failed"); return 1; }
+                if (p.n_sends > NBODY_MAX_RANKS || p.n_recvs > NBODY_MAX_RANKS || p.n_launches > 2) { puts("plan overflow"); return 1; }
+            }
+    { nbody_shard_plan_t p; if (nbody_shard_plan(0, 0, 10, 2, &p) == NBODY_OK || nbody_shard_plan(3, 2, 10, 2, &p) == NBODY_OK) return 1; }
+    { odouble4 Xd[5] = {{0,0,0,1},{1,0,0,1},{0,1,0,1},{0,0,1,1},{1,1,1,1}}, out[3]; oracle_accel_range_f64(Xd, out, 1, 4, 0, 5, 0.002); }
+    { nbody_float3 v3[4], w3[4]; nbody_fill_with_zeroes3(v3, 4); nbody_fill_with_zeroes3(w3, 4); (void)nbody_verify_equality3(v3, w3, 4); (void)nbody_random_float(0.f, 1.f); }
     puts("asan/ubsan: clean");
     return 0;
 }
