@@ -197,7 +197,8 @@ struct SymShape {
 };
 
 constexpr int kSymMinAuto = 16384;  // FAST switches to the symmetric kernel from this many bodies
-constexpr int kSymMaxSlabs = 1024;
+constexpr int kSymMaxSlabs = 2048;
+constexpr size_t kSymMaxWorkspace = (size_t)96 << 30;  // one slab per block: beyond 96 GiB of partial sums the one-sided kernel takes over
 
 // (waves, bodies per lane) instantiated below, largest block first
 const int kSymCand[][2] = {{4, 8}, {2, 8}, {2, 4}, {1, 4}, {1, 2}};
@@ -222,6 +223,7 @@ bool sym_resolve(const nbody_ctx* c, int n, SymShape* out)
     y.nb = (n + y.block - 1) / y.block;
     y.grid = y.nb * (y.nb - 1) / 2 + y.nb;
     if (y.nb < 2 || y.nb > kSymMaxSlabs) return false;
+    if ((size_t)y.nb * (size_t)n * sizeof(float4) > kSymMaxWorkspace) return false;
     *out = y;
     return true;
 }
