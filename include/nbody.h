@@ -264,6 +264,9 @@ int nbody_shard_buffers(nbody_shard* shard, nbody_float4** d_x_full, nbody_float
 /* Every rank passes the same n_total bodies (host memory): positions of all, zero velocity/acceleration; padding
  * bodies are massless and sit on body 0. Synchronous. */
 int nbody_shard_upload(nbody_shard* shard, const nbody_float4* h_bodies);
+/* Velocities of all n_total bodies (host memory; every rank passes the same array and keeps its own block) — to
+ * continue a run: nbody_shard_upload() zeroes them. Synchronous. */
+int nbody_shard_upload_velocity(nbody_shard* shard, const nbody_float4* h_velocity);
 /* Own block (shard entries each, padding included) to host memory. Synchronous. */
 int nbody_shard_download(nbody_shard* shard, nbody_float4* h_x_own, nbody_float4* h_v_own, nbody_float4* h_a_own);
 /* `steps` whole steps, asynchronous (nbody_shard_sync waits for both streams). */

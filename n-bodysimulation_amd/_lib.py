@@ -97,6 +97,7 @@ _SIGNATURES = {
     "nbody_shard_get_plan": (C.c_int, [_p, C.POINTER(ShardPlan)]),
     "nbody_shard_buffers": (C.c_int, [_p] + [C.POINTER(_p)] * 5),
     "nbody_shard_upload": (C.c_int, [_p, _p]),
+    "nbody_shard_upload_velocity": (C.c_int, [_p, _p]),
     "nbody_shard_download": (C.c_int, [_p, _p, _p, _p]),
     "nbody_shard_step": (C.c_int, [_p, C.c_int]),
     "nbody_shard_step_phase": (C.c_int, [_p, C.c_int]),

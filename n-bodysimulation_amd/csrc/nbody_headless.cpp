@@ -140,7 +140,6 @@ int main(int argc, char** argv)
         int ndev = 0;
         ok(nbody_device_count(&ndev));
         if (ngpu > ndev) die("--ngpu " + std::to_string(ngpu) + " but only " + std::to_string(ndev) + " device(s) visible");
-        if (!load.empty()) die("--load resumes a single-device run (velocities are not redistributed)");
         char uid[128];
         ok(nbody_comm_rccl_unique_id(uid));
         std::vector<std::string> errors(ngpu);
@@ -156,6 +155,7 @@ int main(int argc, char** argv)
             if (nbody_comm_rccl_create(&comm, r, ngpu, uid, r) != NBODY_OK) return fail_here("nbody_comm_rccl_create");
             if (nbody_shard_create(&sh, ctx, r, ngpu, n, &comm) != NBODY_OK) return fail_here("nbody_shard_create");
             if (nbody_shard_upload(sh, (const nbody_float4*)bodies) != NBODY_OK) return fail_here("nbody_shard_upload");
+            if (!load.empty() && nbody_shard_upload_velocity(sh, (const nbody_float4*)velocity) != NBODY_OK) return fail_here("nbody_shard_upload_velocity");
             const auto t0 = std::chrono::steady_clock::now();
             if (nbody_shard_step(sh, steps) != NBODY_OK || nbody_shard_sync(sh) != NBODY_OK) return fail_here("nbody_shard_step");
             rank_secs[r] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -290,6 +290,21 @@ int nbody_shard_upload(nbody_shard* s, const nbody_float4* h_bodies)
     return NBODY_OK;
 }
 
+int nbody_shard_upload_velocity(nbody_shard* s, const nbody_float4* h_velocity)
+{
+    if (int rc = check_shard(s)) return rc;
+    const nbody_shard_plan_t& p = s->plan;
+    if (p.n_total > 0 && !h_velocity) return nbody_fail(NBODY_ERR_INVALID, "null host pointer");
+    DeviceScope scope(s->device);
+    HIP_TRY(hipStreamSynchronize(s->compute));
+    HIP_TRY(hipStreamSynchronize(s->comm));
+    if (p.shard == 0) return NBODY_OK;
+    std::vector<nbody_float4> own((size_t)p.shard, nbody_float4{0, 0, 0, 0});  // padding bodies stay at rest
+    for (int i = p.i0; i < p.i1 && i < p.n_total; ++i) own[(size_t)(i - p.i0)] = h_velocity[i];
+    HIP_TRY(hipMemcpy(s->v, own.data(), (size_t)p.shard * sizeof(float4), hipMemcpyHostToDevice));
+    return NBODY_OK;
+}
+
 int nbody_shard_download(nbody_shard* s, nbody_float4* h_x_own, nbody_float4* h_v_own, nbody_float4* h_a_own)
 {
     if (int rc = check_shard(s)) return rc;

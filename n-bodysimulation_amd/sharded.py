@@ -204,6 +204,15 @@ class ShardedSimulation:
         return {"steps": k.value, "all_gather_ms_avg": g.value, "exposed_ms_avg": ge.value, "exchange_ms_avg": x.value,
                 "schedule": {0: "canonical", 1: "onesided", 2: "symmetric"}[self.plan.schedule]}
 
+    def set_velocity(self, velocity: np.ndarray) -> None:
+        """Velocities of all N bodies in the caller's order (to continue a run; construction starts at rest)."""
+        v = np.ascontiguousarray(velocity, np.float32)
+        if v.shape != (self.n, 4):
+            raise ValueError(f"expected ({self.n},4) velocities")
+        if self.perm is not None:
+            v = np.ascontiguousarray(v[self.perm])
+        self._check(self._lib.nbody_shard_upload_velocity(self._h, C.c_void_p(v.ctypes.data)))
+
     def own_state(self):
         """(x, v, a) of the own block (shard rows, padding included) as numpy arrays."""
         out = [np.zeros((self.shard, 4), np.float32) for _ in range(3)]

@@ -89,6 +89,11 @@ def test_headless_sharded_path_over_rccl_and_f64(nb, oracle, tmp_path):
     assert json.loads(out.strip().splitlines()[-1])["ngpu"] == 1
     for ext in ("x", "v", "a"):
         assert np.array_equal(_f4(tmp_path / f"plain.{ext}.f4", n), _f4(tmp_path / f"shard.{ext}.f4", n)), ext
+    # a sharded run resumes from a dump (positions AND velocities) exactly like the single-device one
+    _run([DRIVER, *base[:2], "--steps", "2", "--init", "plummer", "--dt", "0.01", "--seed", "4", "--quiet", "--dump", str(tmp_path / "two")])
+    _run([DRIVER, *base[:2], "--steps", "1", "--dt", "0.01", "--quiet", "--shard", "--load", str(tmp_path / "two"), "--dump", str(tmp_path / "three")])
+    for ext in ("x", "v", "a"):
+        assert np.array_equal(_f4(tmp_path / f"plain.{ext}.f4", n), _f4(tmp_path / f"three.{ext}.f4", n)), ext
     r = subprocess.run([DRIVER, "--n", "4096", "--ngpu", str(torch.cuda.device_count() + 1)], capture_output=True, text=True)
     assert r.returncode != 0 and "device(s) visible" in r.stderr
     n = 1500

@@ -249,6 +249,53 @@ def test_sharded_simulation_multi_rank_over_gloo(nb, oracle, world, n, kernel):
         assert rep["steps"] == steps and rep["schedule"] == ("canonical" if kernel == 1 else "symmetric")
 
 
+def _nccl_worker(rank, world, port, n, steps, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        import nbody_amd
+        x0 = nbody_amd.engine.seeded_bodies(n, 1, 77)
+        sim = nbody_amd.sharded.ShardedSimulation(x0, dt=0.01, eps2=0.002, device=dev)
+        sim.comm_timing(True)
+        sim.step(steps)
+        x, v, a = sim.gather_state()
+        q.put((rank, x, v, a, sim.comm_report()))
+        sim.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs one GPU per rank (RCCL refuses two ranks on one device)")
+def test_sharded_simulation_over_rccl_one_gpu_per_rank(nb, oracle):
+    """Only on a node with several GPUs: the product path over RCCL itself (in-place all-gather of positions, grouped
+    send/recv of the J-side sums), one process per GPU, against the CPU on sampled targets."""
+    import torch.multiprocessing as mp
+    world = min(torch.cuda.device_count(), 8)
+    n, steps = 65536, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, n, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    sim = nb.engine.Simulation(nb.engine.seeded_bodies(n, 1, 77), dt=0.01, eps2=0.002)
+    sim.run(steps)
+    x1, v1, a1 = sim.state()
+    for rank, x, v, a, rep in res:
+        assert np.abs(x - x1)[:, :3].max() <= 1e-6
+        assert np.abs(a - a1)[:, :3].max() / np.abs(a1[:, :3]).max() <= 2e-5
+        assert np.array_equal(x, res[0][1]) and rep["steps"] == steps and rep["schedule"] == "symmetric"
+
+
 def _run_bench(args, timeout=600):
     import json
     import subprocess
