@@ -80,7 +80,8 @@ enum {
 /* ---- the reference boundary ------------------------------------------------------------ */
 
 /* Drop-in for `void simulate(float4* d_bodies, float4* d_accelerations, float4* d_velocity,
- * int N)` (kernel.cuh:2; kernel.cu:628-645): one step on device 0's arrays, in place,
+ * int N)` (kernel.cuh:2; kernel.cu:628-645): one step on the arrays of the caller's CURRENT device, in place
+ * (the reference never selects a device either; the caller's current device is left unchanged),
  * SYNCHRONOUS (returns after the device has finished, like the reference's
  * cudaDeviceSynchronize at kernel.cu:644). d_accelerations is pure output. Uses DT / EPS2 of
  * constants.h:25-26 and the FAST kernel unless the process-wide default context was
@@ -98,7 +99,7 @@ int nbody_simulate(nbody_float4* d_bodies, nbody_float4* d_accelerations, nbody_
 int nbody_simulate_host_legacy(nbody_float4* h_bodies, nbody_float3* h_accelerations,
                                nbody_float3* h_velocity, int n);
 
-/* The context nbody_simulate() uses (created on first use, device 0). */
+/* The context nbody_simulate() uses for the calling thread's current device (one per device, created on first use). */
 int nbody_default_ctx(nbody_ctx** out);
 
 /* ---- contexts ---------------------------------------------------------------------------- */
@@ -118,7 +119,7 @@ int nbody_ctx_set_params(nbody_ctx* ctx, float dt, float eps2);
 int nbody_ctx_set_kernel(nbody_ctx* ctx, int kernel, int tile, int bodies_per_lane, int jsplit);
 
 /* Shape of the symmetric kernel: wave64s per workgroup and stationary bodies per lane; a block is
- * 64*waves*bodies_per_lane bodies. Built: (4,8) (2,8) (2,4) (1,4) (1,2); 0 = auto (the largest block that
+ * 64*waves*bodies_per_lane bodies. Built: (4,8) (2,8) (1,8) (2,4) (1,4) (1,2); 0 = auto (the largest block that
  * still gives 128 blocks). */
 int nbody_ctx_set_symmetric_shape(nbody_ctx* ctx, int waves, int bodies_per_lane);
 

@@ -201,8 +201,8 @@ constexpr int kSymMaxSlabs = 2048;
 constexpr size_t kSymMaxWorkspace = (size_t)96 << 30;  // one slab per block: beyond 96 GiB of partial sums the one-sided kernel takes over
 
 // (waves, bodies per lane) instantiated below, largest block first
-const int kSymCand[][2] = {{4, 8}, {2, 8}, {2, 4}, {1, 4}, {1, 2}};
-constexpr int kSymCands = 5;
+const int kSymCand[][2] = {{4, 8}, {2, 8}, {1, 8}, {2, 4}, {1, 4}, {1, 2}};
+constexpr int kSymCands = 6;
 
 bool sym_resolve(const nbody_ctx* c, int n, SymShape* out)
 {
@@ -354,6 +354,7 @@ int launch_sym_untimed(nbody_ctx* c, const SymShape& y, const nbk::SymParams& p)
     switch (key) {
         case 408: nbk::force_sym<SymPacked<8>, 4><<<y.grid, 256, 0, c->stream>>>(p); break;
         case 208: nbk::force_sym<SymPacked<8>, 2><<<y.grid, 128, 0, c->stream>>>(p); break;
+        case 108: nbk::force_sym<SymPacked<8>, 1><<<y.grid, 64, 0, c->stream>>>(p); break;
         case 204: nbk::force_sym<SymPacked<4>, 2><<<y.grid, 128, 0, c->stream>>>(p); break;
         case 104: nbk::force_sym<SymPacked<4>, 1><<<y.grid, 64, 0, c->stream>>>(p); break;
         case 102: nbk::force_sym<SymPacked<2>, 1><<<y.grid, 64, 0, c->stream>>>(p); break;
@@ -512,7 +513,7 @@ int nbody_ctx_set_symmetric_shape(nbody_ctx* c, int waves, int bodies_per_lane)
     for (int k = 0; k < kSymCands && !ok; ++k)
         ok = (waves == 0 || waves == kSymCand[k][0]) && (bodies_per_lane == 0 || bodies_per_lane == kSymCand[k][1]);
     if (!ok)
-        return fail(NBODY_ERR_CONFIG, "symmetric kernel is built for (waves, bodies_per_lane) in {(4,8),(2,8),(2,4),(1,4),(1,2)} "
+        return fail(NBODY_ERR_CONFIG, "symmetric kernel is built for (waves, bodies_per_lane) in {(4,8),(2,8),(1,8),(2,4),(1,4),(1,2)} "
                     "(fp64: (4,8),(2,4),(1,2) of these); got (%d,%d)", waves, bodies_per_lane);
     c->sym_waves = waves;
     c->sym_bpl = bodies_per_lane;

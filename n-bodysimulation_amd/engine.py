@@ -180,7 +180,7 @@ class Context:
 
 def simulate(d_bodies: torch.Tensor, d_accelerations: torch.Tensor, d_velocity: torch.Tensor, n: Optional[int] = None) -> None:
     """``simulate(d_bodies, d_accelerations, d_velocity, N)`` of TestProject/kernel.cuh:2 —
-    one synchronous in-place step with DT / EPS2 of constants.h:25-26 on device 0."""
+    one synchronous in-place step with DT / EPS2 of constants.h:25-26 on the current device."""
     n = d_bodies.shape[0] if n is None else n
     _check_f4(d_bodies), _check_f4(d_accelerations), _check_f4(d_velocity)
     if n > d_bodies.shape[0]:

@@ -115,7 +115,7 @@ def test_fast_kernel_configurations_agree(nb, oracle, opts):
 
 # ---- the symmetric kernel (every unordered pair once) -----------------------------------------------
 
-@pytest.mark.parametrize("waves,bpl", [(1, 2), (1, 4), (2, 4), (2, 8), (4, 8)])
+@pytest.mark.parametrize("waves,bpl", [(1, 2), (1, 4), (2, 4), (1, 8), (2, 8), (4, 8)])
 @pytest.mark.parametrize("n,init", [(1000, 0), (4099, 1), (6144, 0)])
 def test_symmetric_kernel_shapes_vs_oracle(nb, oracle, waves, bpl, n, init):
     """Every block shape the library builds, on sizes that are not multiples of the block (the last
