@@ -199,10 +199,12 @@ def main():
     dev = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(dev)
     if world > 1:
+        import datetime
+        limit = datetime.timedelta(minutes=5)   # a collective that never completes becomes an error, not a hang
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=limit)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=limit)
 
     n, scaling = default_workload(world, args.n, args.scaling)
     x0 = nbody_amd.engine.seeded_bodies(n, args.init, 12345)
