@@ -236,6 +236,50 @@ def test_accel_cross_two_disjoint_sets(nb, oracle, waves, bpl, n, i0, i1, j0, co
     assert np.array_equal(aj.cpu().numpy(), gj)
 
 
+def test_randomised_symmetric_and_cross_cases(nb, oracle):
+    """30 random cases — size, block shape, length scale (1e-2 ... 1e5), mass range, zero and negative masses,
+    coincident bodies: the symmetric kernel over the whole set, and nbody_accel_cross over a random split of it, against
+    the fp64-accumulated CPU sums; the two sides of every cross call balance (sum of m*a over both sets = 0)."""
+    rng = np.random.default_rng(2718)
+    shapes = [(1, 2), (1, 4), (2, 4), (1, 8), (2, 8), (4, 8)]
+    for case in range(30):
+        w, b = shapes[case % len(shapes)]
+        n = int(rng.integers(2 * 64 * w * b, 2 * 64 * w * b + 3000))
+        scale = 10.0 ** rng.uniform(-2, 5)
+        x0 = (rng.uniform(-1, 1, (n, 4)) * scale).astype(np.float32)
+        x0[:, 3] = (10.0 ** rng.uniform(-3, 9, n)).astype(np.float32)
+        x0[rng.integers(0, n, 5), 3] = 0.0                      # massless bodies
+        x0[rng.integers(0, n, 3), 3] *= -1.0                    # and a few negative masses: plain arithmetic, no special cases
+        x0[7, :3] = x0[3, :3]                                   # coincident pair: softening keeps it finite
+        eps2 = float(np.float32((0.045 * scale / 1e5) ** 2 + 1e-12)) if case % 3 else 0.002
+        ctx = nb.engine.Context(eps2=eps2, kernel=nb.KERNEL_SYMMETRIC)
+        ctx.set_symmetric_shape(w, b)
+        x = torch.from_numpy(x0).cuda()
+        a = torch.zeros_like(x)
+        ctx.accel_range(x, a, 0, n, 0, n)
+        truth = oracle.accel_range(x0, 0, n, eps2=eps2, f64acc=True)
+        amax = np.abs(truth[:, :3]).max()
+        ctx.sync()
+        assert np.abs(a.cpu().numpy() - truth)[:, :3].max() / amax <= 2e-5, (case, n, w, b, scale)
+        # a random split into targets [i0,i1) and a wrapped run of everything else
+        i0 = int(rng.integers(0, n - 10)); i1 = int(rng.integers(i0 + 1, min(n, i0 + n // 2) + 1))
+        ai = torch.zeros((i1 - i0, 4), device="cuda")
+        aj = torch.zeros((n - (i1 - i0), 4), device="cuda")
+        ctx.accel_cross(x, ai, i0, i1, False, i1 % n, n - (i1 - i0), aj)
+        ctx.sync()
+        run = (np.arange(n - (i1 - i0)) + i1) % n
+        xs = np.ascontiguousarray(np.concatenate([x0[i0:i1], x0[run]]))
+        ni = i1 - i0
+        want_i = oracle.accel_range(xs, 0, ni, ni, n, eps2=eps2, f64acc=True)
+        want_j = oracle.accel_range(xs, ni, n, 0, ni, eps2=eps2, f64acc=True)
+        gi, gj = ai.cpu().numpy(), aj.cpu().numpy()
+        assert np.abs(gi - want_i)[:, :3].max() <= 2e-5 * max(np.abs(want_i[:, :3]).max(), amax * 1e-3), (case, "i")
+        assert np.abs(gj - want_j)[:, :3].max() <= 2e-5 * max(np.abs(want_j[:, :3]).max(), amax * 1e-3), (case, "j")
+        mi, mj = xs[:ni, 3:4].astype(np.float64), xs[ni:, 3:4].astype(np.float64)
+        net = np.abs((mi * gi[:, :3]).sum(0) + (mj * gj[:, :3]).sum(0)).max()
+        assert net <= 1e-5 * ((np.abs(mi) * np.abs(gi[:, :3])).sum() + (np.abs(mj) * np.abs(gj[:, :3])).sum()), case
+
+
 def test_accel_cross_rejects_overlap_and_strict(nb):
     x = torch.zeros((1000, 4), device="cuda")
     a = torch.zeros((100, 4), device="cuda")
