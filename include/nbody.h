@@ -151,6 +151,15 @@ int nbody_step(nbody_ctx* ctx, nbody_float4* d_bodies, nbody_float4* d_accelerat
 int nbody_accel_range(nbody_ctx* ctx, const nbody_float4* d_bodies, nbody_float4* d_acc_out, int i0,
                       int i1, int j0, int j1, int accumulate);
 
+/* nbody_accel_range(i0, i1, i0, i1) — a block against itself — issued in `nparts` launches, so that a caller can put
+ * other work of the same stream between them (the sharded step hides its exchange behind the second half). Call with
+ * part = 0 .. nparts-1 in order on one stream; the LAST part adds the partial sums up and writes d_acc_out (with
+ * accumulate != 0: continues the sums already there). Other launches of this context may run in between, also
+ * nbody_accel_cross (it has a workspace of its own); another nbody_accel_range / nbody_step may not. Where the symmetric
+ * kernel does not apply (kernel id, size) part 0 does the whole evaluation and the others nothing. */
+int nbody_accel_square_part(nbody_ctx* ctx, const nbody_float4* d_bodies, nbody_float4* d_acc_out, int i0, int i1,
+                            int accumulate, int part, int nparts);
+
 /* The same with a source run that may wrap around the end of the array: sources j0, j0+1, ...,
  * j0+count-1, indices taken modulo n_total. One launch covers "every block except my own" for a rank
  * of the sharded step (j0 = end of the own block, count = n_total - block). */
@@ -186,10 +195,11 @@ int nbody_ctx_get(nbody_ctx* ctx, int* device, int* kernel, void** hip_stream);
  *
  *   schedule SYMMETRIC (ctx kernel FAST or SYMMETRIC) — every unordered pair of bodies evaluated once in the machine:
  *     comm stream     all-gather of positions (in place, shard*16 B per rank)        | overlapped with
- *     compute stream  own block x own block, symmetric kernel                        | each other
+ *     compute stream  own block x own block, symmetric kernel, FIRST half of its tasks | each other
  *     compute stream  own block x the blocks r+1 .. r+(world-1)/2 (for an even world the block half-way round is
  *                     shared between its two ranks): nbody_accel_cross — the J-side sums belong to OTHER ranks
- *     comm stream     exchange: those J-side sums go to their owners, this rank's arrive (grouped send/recv)
+ *     comm stream     exchange: those J-side sums go to their owners, this rank's arrive   | overlapped with
+ *     compute stream  own block x own block, SECOND half of its tasks, slab sum            | each other
  *     compute stream  add the received sums in a fixed order, integrate the own block
  *   schedule ONESIDED (ctx kernel ONESIDED): all-gather overlapped with own x own, then own x everybody else in ONE
  *     one-sided launch over a source run that wraps around the end of the array; no exchange.
@@ -277,9 +287,11 @@ int nbody_shard_step(nbody_shard* shard, int steps);
 int nbody_shard_step_phase(nbody_shard* shard, int phase);
 int nbody_shard_sync(nbody_shard* shard);
 /* Per-step communication timing (events on the two streams): mean all-gather time and the part of it not hidden
- * behind the own-block pass; mean exchange time (exposed by construction). Any out pointer may be NULL. */
+ * behind the first half of the own-block pass; mean exchange time and the part of it not hidden behind the second
+ * half. Any out pointer may be NULL. */
 int nbody_shard_comm_timing(nbody_shard* shard, int enable);
-int nbody_shard_comm_report(nbody_shard* shard, int* steps, double* gather_ms, double* gather_exposed_ms, double* exchange_ms);
+int nbody_shard_comm_report(nbody_shard* shard, int* steps, double* gather_ms, double* gather_exposed_ms, double* exchange_ms,
+                            double* exchange_exposed_ms);
 
 /* ---- fp64 variant (the build's own; the reference has no double path) -------------------- */
 int nbody_step_f64(nbody_ctx* ctx, nbody_double4* d_bodies, nbody_double4* d_accelerations,

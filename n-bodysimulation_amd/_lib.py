@@ -83,6 +83,7 @@ _SIGNATURES = {
     "nbody_ctx_set_graph": (C.c_int, [_p, C.c_int]),
     "nbody_step": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int]),
     "nbody_accel_range": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "nbody_accel_square_part": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "nbody_accel_wrapped": (C.c_int, [_p, _p, C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "nbody_accel_cross": (C.c_int, [_p, _p, C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "nbody_integrate_range": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int]),
@@ -103,7 +104,7 @@ _SIGNATURES = {
     "nbody_shard_step_phase": (C.c_int, [_p, C.c_int]),
     "nbody_shard_sync": (C.c_int, [_p]),
     "nbody_shard_comm_timing": (C.c_int, [_p, C.c_int]),
-    "nbody_shard_comm_report": (C.c_int, [_p, C.POINTER(C.c_int)] + [C.POINTER(C.c_double)] * 3),
+    "nbody_shard_comm_report": (C.c_int, [_p, C.POINTER(C.c_int)] + [C.POINTER(C.c_double)] * 4),
     "nbody_ctx_timing": (C.c_int, [_p, C.c_int]),
     "nbody_ctx_timing_read": (C.c_int, [_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "nbody_step_f64": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_double, C.c_double]),

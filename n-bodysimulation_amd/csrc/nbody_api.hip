@@ -95,6 +95,8 @@ struct nbody_ctx {
     int num_cu = 256;
     void* slabs = nullptr;     // workspace: jsplit slabs of n_targets float4 (or double4)
     size_t slab_bytes = 0;
+    void* xslabs = nullptr;    // workspace of nbody_accel_cross (its own, so that a square evaluation issued in parts
+    size_t xslab_bytes = 0;    // around cross launches keeps its partial sums)
     bool legacy_eps = false;     // strict kernel evaluates `+ EPS2` as the older snapshot does
     void* legacy_buf = nullptr;  // device staging of the host-pointer adapter
     size_t legacy_bytes = 0;
@@ -277,6 +279,20 @@ bool sym_wanted(const nbody_ctx* c, int n, SymShape* out)
     return false;
 }
 
+int ensure_xslabs(nbody_ctx* c, size_t bytes)
+{
+    if (bytes <= c->xslab_bytes) return NBODY_OK;
+    if (c->xslabs) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipFree(c->xslabs));
+        c->xslabs = nullptr;
+        c->xslab_bytes = 0;
+    }
+    HIP_TRY(hipMalloc(&c->xslabs, bytes));
+    c->xslab_bytes = bytes;
+    return NBODY_OK;
+}
+
 int ensure_slabs(nbody_ctx* c, size_t bytes)
 {
     if (bytes <= c->slab_bytes) return NBODY_OK;
@@ -347,9 +363,13 @@ int launch_force_untimed(nbody_ctx* c, const Shape& s, const nbk::ForceParams& p
     return NBODY_OK;
 }
 
-int launch_sym_untimed(nbody_ctx* c, const SymShape& y, const nbk::SymParams& p)
+// launches tasks [p.task0, p.task0 + ntasks) of the shape's task list (ntasks < 0: all of them from p.task0)
+int launch_sym_untimed(nbody_ctx* c, const SymShape& y0, const nbk::SymParams& p, int ntasks = -1)
 {
     using nbk::SymPacked;
+    SymShape y = y0;
+    y.grid = ntasks >= 0 ? ntasks : y0.grid - p.task0;
+    if (y.grid <= 0) return NBODY_OK;
     const int key = y.waves * 100 + y.bpl;
     switch (key) {
         case 408: nbk::force_sym<SymPacked<8>, 4><<<y.grid, 256, 0, c->stream>>>(p); break;
@@ -364,10 +384,10 @@ int launch_sym_untimed(nbody_ctx* c, const SymShape& y, const nbk::SymParams& p)
     return NBODY_OK;
 }
 
-int launch_sym(nbody_ctx* c, const SymShape& y, const nbk::SymParams& p)
+int launch_sym(nbody_ctx* c, const SymShape& y, const nbk::SymParams& p, int ntasks = -1)
 {
     if (int rc = time_mark(c)) return rc;
-    if (int rc = launch_sym_untimed(c, y, p)) return rc;
+    if (int rc = launch_sym_untimed(c, y, p, ntasks)) return rc;
     return time_mark(c);
 }
 
@@ -450,6 +470,7 @@ int nbody_ctx_destroy(nbody_ctx* c)
     if (!c) return NBODY_OK;
     DeviceGuard guard(c->device);
     if (c->slabs) (void)hipFree(c->slabs);
+    if (c->xslabs) (void)hipFree(c->xslabs);
     if (c->legacy_buf) (void)hipFree(c->legacy_buf);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -670,6 +691,38 @@ int nbody_accel_range(nbody_ctx* c, const nbody_float4* d_bodies, nbody_float4* 
     return accel_impl(c, d_bodies, d_acc_out, i0, i1, j0, j1, 0, accumulate);
 }
 
+int nbody_accel_square_part(nbody_ctx* c, const nbody_float4* d_bodies, nbody_float4* d_acc_out, int i0, int i1, int accumulate,
+                            int part, int nparts)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (i0 < 0 || i1 < i0 || nparts < 1 || part < 0 || part >= nparts)
+        return fail(NBODY_ERR_INVALID, "bad square part: i[%d,%d) part %d of %d", i0, i1, part, nparts);
+    if (i1 == i0) return NBODY_OK;
+    if (!d_bodies || !d_acc_out) return fail(NBODY_ERR_INVALID, "null device pointer");
+    const int nt = i1 - i0;
+    SymShape y{};
+    if (!sym_wanted(c, nt, &y))  // no symmetric kernel for this size / kernel id: the first part is the whole evaluation
+        return part == 0 ? accel_impl(c, d_bodies, d_acc_out, i0, i1, i0, i1, 0, accumulate) : NBODY_OK;
+    ON_DEVICE(c);
+    if (int rc = ensure_slabs(c, (size_t)y.nb * nt * sizeof(float4))) return rc;
+    nbk::SymParams sp{};
+    sym_square_params(&sp, reinterpret_cast<const float4*>(d_bodies), i0, nt, y, static_cast<float4*>(c->slabs), c->eps2);
+    const long t0 = (long)y.grid * part / nparts, t1 = (long)y.grid * (part + 1) / nparts;
+    sp.task0 = (int)t0;
+    if (int rc = launch_sym(c, y, sp, (int)(t1 - t0))) return rc;
+    if (part != nparts - 1) return NBODY_OK;
+    nbk::ReduceParams r{};   // every part has been issued on this stream by now: add the slabs in index order
+    r.out = reinterpret_cast<float4*>(d_acc_out);
+    r.slabs = static_cast<const float4*>(c->slabs);
+    r.nslab = y.nb;
+    r.slab_stride = nt;
+    r.n = nt;
+    r.accumulate = accumulate ? 1 : 0;
+    nbk::reduce_slabs<<<(nt + nbk::kWG - 1) / nbk::kWG, nbk::kWG, 0, c->stream>>>(r);
+    HIP_TRY(hipGetLastError());
+    return NBODY_OK;
+}
+
 int nbody_accel_wrapped(nbody_ctx* c, const nbody_float4* d_bodies, int n_total, nbody_float4* d_acc_out, int i0, int i1,
                         int j0, int count, int accumulate)
 {
@@ -708,11 +761,11 @@ int nbody_accel_cross(nbody_ctx* c, const nbody_float4* d_bodies, int n_total, n
     if (!sym_resolve_cross(c, ni, count, &y, &nbj)) return fail(NBODY_ERR_CONFIG, "no symmetric kernel shape for %d x %d bodies", ni, count);
     // workspace: nbj I-side slabs of ni bodies, then nbi J-side slabs of `count` bodies
     const size_t islabs = (size_t)nbj * ni, jslabs = (size_t)y.nb * count;
-    if (int rc = ensure_slabs(c, (islabs + jslabs) * sizeof(float4))) return rc;
+    if (int rc = ensure_xslabs(c, (islabs + jslabs) * sizeof(float4))) return rc;
     nbk::SymParams sp{};
     sp.x = reinterpret_cast<const float4*>(d_bodies);
-    sp.slabs_i = static_cast<float4*>(c->slabs);
-    sp.slabs_j = static_cast<float4*>(c->slabs) + islabs;
+    sp.slabs_i = static_cast<float4*>(c->xslabs);
+    sp.slabs_j = static_cast<float4*>(c->xslabs) + islabs;
     sp.ni = ni; sp.nj = count;
     sp.i0 = i0; sp.j0 = j0;
     sp.wrap = n_total;

@@ -311,6 +311,7 @@ struct SymParamsT {
     int wrap;             // 0, or the array length: a J index at or beyond it continues at body 0
     int nbi, nbj;         // blocks of B bodies on each side
     int stride_i, stride_j;
+    int task0;            // first task of this launch (a grid may cover a sub-range of the task list: task = task0 + blockIdx.x)
     int rect;             // 0: ONE range (I range == J run): block pairs I < J once + the diagonal blocks one-sided
                           //    (nbi == nbj == nb, slabs_i == slabs_j: slab J gets the I-side sums, slab I the J-side sums)
                           // 1: TWO disjoint ranges: every (I, J) block pair, symmetric; slab J of slabs_i, slab I of slabs_j
@@ -577,7 +578,7 @@ __global__ void __launch_bounds__(64 * W, MINW) force_sym(const SymParamsT<typen
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     int I, J;
     bool diag = false;
-    const int task = blockIdx.x;
+    const int task = p.task0 + (int)blockIdx.x;
     if (p.rect) {
         I = task % p.nbi;
         J = task / p.nbi;

@@ -72,7 +72,7 @@ struct nbody_shard {
     // communication timing
     bool timing = false;
     struct StepEvents {
-        hipEvent_t g0, g1, local_done, x0, x1;
+        hipEvent_t g0, g1, local_done, x0, x1, own_done;
         bool gathered, exchanged;
     };
     std::vector<StepEvents> timed;
@@ -100,7 +100,7 @@ int phase_gather(nbody_shard* s)
     s->gather_posted = false;
     if (s->timing) {
         nbody_shard::StepEvents ev{};
-        for (hipEvent_t* e : {&ev.g0, &ev.g1, &ev.local_done, &ev.x0, &ev.x1})
+        for (hipEvent_t* e : {&ev.g0, &ev.g1, &ev.local_done, &ev.x0, &ev.x1, &ev.own_done})
             if (int rc = new_event(e, true)) return rc;
         s->timed.push_back(ev);
     }
@@ -127,13 +127,22 @@ int phase_compute(nbody_shard* s)
         if (s->gather_posted) HIP_TRY(hipStreamWaitEvent(s->compute, s->ev_gathered, 0));
         return nbody_accel_range(c, nb(s->x), nb(s->a), p.i0, p.i1, 0, p.n_pad, 0);
     }
-    // own block against itself while the positions of the others are still on their way
-    if (int rc = nbody_accel_range(c, nb(s->x), nb(s->a), p.i0, p.i1, p.i0, p.i1, 0)) return rc;
+    if (p.schedule == NBODY_SCHEDULE_ONESIDED) {
+        // own block against itself while the positions of the others are still on their way
+        if (int rc = nbody_accel_range(c, nb(s->x), nb(s->a), p.i0, p.i1, p.i0, p.i1, 0)) return rc;
+        if (s->timing && s->gather_posted) HIP_TRY(hipEventRecord(s->timed.back().local_done, s->compute));
+        if (s->gather_posted) HIP_TRY(hipStreamWaitEvent(s->compute, s->ev_gathered, 0));
+        if (p.world == 1) return NBODY_OK;
+        // everybody else in one launch: sources i1, i1+1, ... wrapping round to i0-1
+        return nbody_accel_wrapped(c, nb(s->x), p.n_pad, nb(s->a), p.i0, p.i1, p.i1 % p.n_pad, p.n_pad - p.shard, 1);
+    }
+    // symmetric schedule. The own block against itself is issued in two halves: the first hides the all-gather, the
+    // second (phase_finish) hides the exchange. The sums land in `a` in a fixed order: cross launches, own block, received.
+    HIP_TRY(hipMemsetAsync(s->a, 0, (size_t)p.shard * sizeof(float4), s->compute));
+    if (int rc = nbody_accel_square_part(c, nb(s->x), nb(s->a), p.i0, p.i1, 1, 0, 2)) return rc;
     if (s->timing && s->gather_posted) HIP_TRY(hipEventRecord(s->timed.back().local_done, s->compute));
     if (s->gather_posted) HIP_TRY(hipStreamWaitEvent(s->compute, s->ev_gathered, 0));
     if (p.world == 1) return NBODY_OK;
-    if (p.schedule == NBODY_SCHEDULE_ONESIDED)  // everybody else in one launch: sources i1, i1+1, ... wrapping round to i0-1
-        return nbody_accel_wrapped(c, nb(s->x), p.n_pad, nb(s->a), p.i0, p.i1, p.i1 % p.n_pad, p.n_pad - p.shard, 1);
     for (int l = 0; l < p.n_launches; ++l) {
         const nbody_cross_launch& L = p.launch[l];
         if (int rc = nbody_accel_cross(c, nb(s->x), p.n_pad, nb(s->a + (L.i0 - p.i0)), L.i0, L.i1, 1, L.j0, L.count,
@@ -164,6 +173,10 @@ int phase_finish(nbody_shard* s)
 {
     const nbody_shard_plan_t& p = s->plan;
     if (p.shard == 0) return NBODY_OK;
+    if (p.schedule == NBODY_SCHEDULE_SYMMETRIC) {  // second half of the own block (+ its slab sum), while the exchange runs
+        if (int rc = nbody_accel_square_part(s->ctx, nb(s->x), nb(s->a), p.i0, p.i1, 1, 1, 2)) return rc;
+        if (s->timing && !s->timed.empty() && s->timed.back().exchanged) HIP_TRY(hipEventRecord(s->timed.back().own_done, s->compute));
+    }
     if (p.world > 1 && p.schedule == NBODY_SCHEDULE_SYMMETRIC) {
         HIP_TRY(hipStreamWaitEvent(s->compute, s->ev_exchanged, 0));
         for (int k = 0; k < p.n_recvs; ++k) {  // fixed order: nearest preceding rank first
@@ -239,7 +252,7 @@ int nbody_shard_destroy(nbody_shard* s)
     for (hipEvent_t ev : {s->ev_integrated, s->ev_gathered, s->ev_cross, s->ev_exchanged})
         if (ev) (void)hipEventDestroy(ev);
     for (auto& t : s->timed)
-        for (hipEvent_t ev : {t.g0, t.g1, t.local_done, t.x0, t.x1})
+        for (hipEvent_t ev : {t.g0, t.g1, t.local_done, t.x0, t.x1, t.own_done})
             if (ev) (void)hipEventDestroy(ev);
     if (s->comm) (void)hipStreamDestroy(s->comm);
     delete s;
@@ -361,18 +374,19 @@ int nbody_shard_comm_timing(nbody_shard* s, int enable)
     if (int rc = check_shard(s)) return rc;
     if (int rc = nbody_shard_sync(s)) return rc;
     for (auto& t : s->timed)
-        for (hipEvent_t ev : {t.g0, t.g1, t.local_done, t.x0, t.x1})
+        for (hipEvent_t ev : {t.g0, t.g1, t.local_done, t.x0, t.x1, t.own_done})
             if (ev) (void)hipEventDestroy(ev);
     s->timed.clear();
     s->timing = enable != 0;
     return NBODY_OK;
 }
 
-int nbody_shard_comm_report(nbody_shard* s, int* steps, double* gather_ms, double* gather_exposed_ms, double* exchange_ms)
+int nbody_shard_comm_report(nbody_shard* s, int* steps, double* gather_ms, double* gather_exposed_ms, double* exchange_ms,
+                            double* exchange_exposed_ms)
 {
     if (int rc = check_shard(s)) return rc;
     if (int rc = nbody_shard_sync(s)) return rc;
-    double g = 0, ge = 0, x = 0;
+    double g = 0, ge = 0, x = 0, xe = 0;
     int ng = 0, nx = 0;
     for (auto& t : s->timed) {
         float ms = 0;
@@ -386,6 +400,8 @@ int nbody_shard_comm_report(nbody_shard* s, int* steps, double* gather_ms, doubl
         if (t.exchanged) {
             HIP_TRY(hipEventElapsedTime(&ms, t.x0, t.x1));
             x += ms;
+            // not hidden = from the end of the second half of the own block to the end of the exchange
+            if (hipEventElapsedTime(&ms, t.own_done, t.x1) == hipSuccess && ms > 0) xe += ms;
             ++nx;
         }
     }
@@ -393,6 +409,7 @@ int nbody_shard_comm_report(nbody_shard* s, int* steps, double* gather_ms, doubl
     if (gather_ms) *gather_ms = ng ? g / ng : 0.0;
     if (gather_exposed_ms) *gather_exposed_ms = ng ? ge / ng : 0.0;
     if (exchange_ms) *exchange_ms = nx ? x / nx : 0.0;
+    if (exchange_exposed_ms) *exchange_exposed_ms = nx ? xe / nx : 0.0;
     return NBODY_OK;
 }
 

@@ -12,9 +12,10 @@ side: it asks the library for the rank's plan, hands it the two collectives as c
 
     per step, on rank r (schedule SYMMETRIC, the default)          stream
       all_gather(X_full <- own block), in place, S*16 B per rank     comm     | overlapped
-      A  = own block x own block, every unordered pair once          compute  |
-      A += own block x blocks r+1 .. r+(G-1)/2 (mod G), pairs once   compute  -> J-side sums for OTHER ranks
-      exchange: J-side sums to their owners, mine arrive             comm     (grouped send/recv)
+      own block x own block, first half of its block pairs           compute  |
+      A  = own block x blocks r+1 .. r+(G-1)/2 (mod G), pairs once   compute  -> J-side sums for OTHER ranks
+      exchange: J-side sums to their owners, mine arrive             comm     | overlapped (grouped send/recv)
+      A += own block x own block (second half, then its slab sum)    compute  |
       A += received sums (fixed order); v += (dt/2) a ; x += dt v    compute
 
 so every unordered pair of bodies is evaluated exactly once in the whole machine. With the ONESIDED
@@ -199,9 +200,10 @@ class ShardedSimulation:
 
     def comm_report(self) -> dict:
         """Per-step means: all-gather time, the part of it not hidden behind the own-block pass, exchange time."""
-        k, g, ge, x = C.c_int(), C.c_double(), C.c_double(), C.c_double()
-        self._check(self._lib.nbody_shard_comm_report(self._h, C.byref(k), C.byref(g), C.byref(ge), C.byref(x)))
+        k, g, ge, x, xe = C.c_int(), C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        self._check(self._lib.nbody_shard_comm_report(self._h, C.byref(k), C.byref(g), C.byref(ge), C.byref(x), C.byref(xe)))
         return {"steps": k.value, "all_gather_ms_avg": g.value, "exposed_ms_avg": ge.value, "exchange_ms_avg": x.value,
+                "exchange_exposed_ms_avg": xe.value,
                 "schedule": {0: "canonical", 1: "onesided", 2: "symmetric"}[self.plan.schedule]}
 
     def set_velocity(self, velocity: np.ndarray) -> None:
