@@ -161,6 +161,12 @@ def test_callback_ranks_symmetric_at_block_sizes_the_bench_uses(nb, oracle):
     m = x0[:, 3:4].astype(np.float64)
     assert np.abs((m * a[:, :3]).sum(0)).max() / (m * np.abs(a[:, :3])).sum() < 1e-6
     ranks.close()
+    # the same run again: bit-identical (fixed task lists, fixed order of the slab sums and of the received sums)
+    again = _OneThreadRanks(nb, x0, world, nb.KERNEL_FAST, 0.01, 0.002)
+    again.step(1)
+    x2, v2, a2 = again.state(n)
+    again.close()
+    assert np.array_equal(a, a2) and np.array_equal(x, x2) and np.array_equal(v, v2)
 
 
 def test_native_rccl_comm_with_one_rank(nb):
