@@ -9,7 +9,7 @@
 namespace {
 
 // utils.cpp:6
-inline float random_float(float lo, float hi) { return ((float)rand() / RAND_MAX) * (hi - lo) + lo; }
+inline float random_float(float lo, float hi) { return ((float)rand() / (float)RAND_MAX) * (hi - lo) + lo; }  // RAND_MAX converts to float exactly as the reference's implicit conversion does
 
 // splitmix64: small, portable, seedable
 struct SplitMix64 {
