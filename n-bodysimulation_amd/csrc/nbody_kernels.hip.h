@@ -477,7 +477,9 @@ struct SymScalar {
 
 // Double-precision arithmetic for the rotation kernel (the build's own fp64 variant, BASELINE configs[4]).
 // d^(-3/2): v_rsq_f64 seed (about 5e-8 relative, tools/rsq64_probe.hip) and ONE third-order step
-// y <- y (1 + r/2 + 3 r^2/8), r = 1 - d y^2 (error 5/16 r^3 ~ 1e-22): 5 ops, against 7 for two Newton steps.
+// y <- y (1 + r/2 + 3 r^2/8), r = 1 - d y^2 (error 5/16 r^3 ~ 1e-22), then the cube: 7 ops, against 9 with two Newton
+// steps. (Correcting the cube directly — w = q^3 (1 + 3r/2 + 15r^2/8), 6 ops — measured 2.8 % SLOWER: 27.9 vs 27.2 ms
+// per step at N=262144, same box, alternating runs; two more values stay live per pair.)
 template <int BPL_>
 struct SymF64 {
     using S = double;
