@@ -236,7 +236,9 @@ def main():
         sym64 = kernel != nbody_amd.KERNEL_ONESIDED and (n >= 16384 or kernel == nbody_amd.KERNEL_SYMMETRIC)
         info = {"symmetric": sym64, "slabs": args.jsplit or "auto", "evaluated_pairs": float(n) * n}
         if sym64:   # the double-precision rotation kernel: blocks of 64*waves*bpl bodies, each unordered pair once
-            cands = [(4, 8), (2, 4), (1, 2)]
+            cands = [(4, 6), (2, 4), (1, 2)]
+            if (args.sym_waves, args.sym_bpl) == (4, 8):
+                cands = [(4, 8)]
             pick = next(((w, b) for (w, b) in cands if (not args.sym_waves or w == args.sym_waves) and (not args.sym_bpl or b == args.sym_bpl)
                          and n >= 128 * 64 * w * b), cands[-1])
             blk = 64 * pick[0] * pick[1]

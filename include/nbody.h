@@ -119,8 +119,8 @@ int nbody_ctx_set_params(nbody_ctx* ctx, float dt, float eps2);
 int nbody_ctx_set_kernel(nbody_ctx* ctx, int kernel, int tile, int bodies_per_lane, int jsplit);
 
 /* Shape of the symmetric kernel: wave64s per workgroup and stationary bodies per lane; a block is
- * 64*waves*bodies_per_lane bodies. Built: (4,8) (2,8) (1,8) (2,4) (1,4) (1,2); 0 = auto (the largest block that
- * still gives 128 blocks). */
+ * 64*waves*bodies_per_lane bodies. Built: (4,10) (4,8) (2,10) (2,8) (1,8) (2,4) (1,4) (1,2); 0 = auto (the
+ * largest block that still gives 72 blocks). The fp64 step takes (4,6) (4,8) (2,4) (1,2). */
 int nbody_ctx_set_symmetric_shape(nbody_ctx* ctx, int waves, int bodies_per_lane);
 
 /* Launch on this HIP stream (a hipStream_t passed as void*; NULL = the context's own stream). */

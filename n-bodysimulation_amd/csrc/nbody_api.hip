@@ -203,8 +203,8 @@ constexpr int kSymMaxSlabs = 2048;
 constexpr size_t kSymMaxWorkspace = (size_t)96 << 30;  // one slab per block: beyond 96 GiB of partial sums the one-sided kernel takes over
 
 // (waves, bodies per lane) instantiated below, largest block first
-const int kSymCand[][2] = {{4, 8}, {2, 8}, {1, 8}, {2, 4}, {1, 4}, {1, 2}};
-constexpr int kSymCands = 6;
+const int kSymCand[][2] = {{4, 10}, {4, 8}, {2, 10}, {2, 8}, {1, 8}, {2, 4}, {1, 4}, {1, 2}};
+constexpr int kSymCands = 8;
 
 bool sym_resolve(const nbody_ctx* c, int n, SymShape* out)
 {
@@ -212,10 +212,12 @@ bool sym_resolve(const nbody_ctx* c, int n, SymShape* out)
     for (int k = 0; k < kSymCands; ++k) {
         if ((c->sym_waves && kSymCand[k][0] != c->sym_waves) || (c->sym_bpl && kSymCand[k][1] != c->sym_bpl)) continue;
         pick = k;
-        // the largest block that still gives 128 blocks (8256 tasks): measured best at every size from 16384 to
-        // 262144 bodies (tools/smalln_probe.py, profiles/r02_smalln_probe_a.jsonl) — with 64 blocks the 2080 tasks
-        // fall 2 or 3 to a SIMD and the 3s set the kernel time
-        if ((long)n >= 128L * 64 * kSymCand[k][0] * kSymCand[k][1]) break;
+        // the first shape of the list (largest block first) that still gives 72 blocks: measured best or within 0.5 % of the
+        // best at every size from 16384 to 1048576 bodies (tools/smalln_probe.py, profiles/r02_smalln_probe_{a,b}.jsonl,
+        // profiles/r02_shape_probe_large.jsonl): 10 bodies per lane and 2560-body blocks from 196608 bodies (+2.6 % over 8
+        // per lane at 262144), 1280-body blocks around 100k, single-wave 512-body blocks at 65536; with fewer blocks the
+        // tasks fall unevenly on the SIMDs and the fullest ones set the kernel time
+        if ((long)n >= 72L * 64 * kSymCand[k][0] * kSymCand[k][1]) break;
     }
     if (pick < 0) return false;
     SymShape y{};
@@ -372,7 +374,9 @@ int launch_sym_untimed(nbody_ctx* c, const SymShape& y0, const nbk::SymParams& p
     if (y.grid <= 0) return NBODY_OK;
     const int key = y.waves * 100 + y.bpl;
     switch (key) {
+        case 410: nbk::force_sym<SymPacked<10>, 4><<<y.grid, 256, 0, c->stream>>>(p); break;
         case 408: nbk::force_sym<SymPacked<8>, 4><<<y.grid, 256, 0, c->stream>>>(p); break;
+        case 210: nbk::force_sym<SymPacked<10>, 2><<<y.grid, 128, 0, c->stream>>>(p); break;
         case 208: nbk::force_sym<SymPacked<8>, 2><<<y.grid, 128, 0, c->stream>>>(p); break;
         case 108: nbk::force_sym<SymPacked<8>, 1><<<y.grid, 64, 0, c->stream>>>(p); break;
         case 204: nbk::force_sym<SymPacked<4>, 2><<<y.grid, 128, 0, c->stream>>>(p); break;
@@ -418,7 +422,7 @@ const char* nbody_last_error(void) { return g_err; }
 
 const char* nbody_version(void)
 {
-    return "nbody_hip 0.2 gfx950 fast=symmetric-dpp(w4,bpl8)|onesided-lds-packed(bpl4,tile2048,u8) strict=ieee-seq f64=lds";
+    return "nbody_hip 0.2 gfx950 fast=symmetric-dpp(w4,bpl10)|onesided-lds-packed(bpl4,tile2048,u8) strict=ieee-seq f64=symmetric-dpp(w4,bpl6)|lds";
 }
 
 int nbody_device_count(int* count)
@@ -533,9 +537,10 @@ int nbody_ctx_set_symmetric_shape(nbody_ctx* c, int waves, int bodies_per_lane)
     bool ok = (waves == 0 && bodies_per_lane == 0);
     for (int k = 0; k < kSymCands && !ok; ++k)
         ok = (waves == 0 || waves == kSymCand[k][0]) && (bodies_per_lane == 0 || bodies_per_lane == kSymCand[k][1]);
+    if (waves == 4 && bodies_per_lane == 6) ok = true;  // fp64 only
     if (!ok)
-        return fail(NBODY_ERR_CONFIG, "symmetric kernel is built for (waves, bodies_per_lane) in {(4,8),(2,8),(1,8),(2,4),(1,4),(1,2)} "
-                    "(fp64: (4,8),(2,4),(1,2) of these); got (%d,%d)", waves, bodies_per_lane);
+        return fail(NBODY_ERR_CONFIG, "symmetric kernel is built for (waves, bodies_per_lane) in {(4,10),(4,8),(2,10),(2,8),(1,8),(2,4),(1,4),(1,2)} "
+                    "(fp64: (4,6),(4,8),(2,4),(1,2)); got (%d,%d)", waves, bodies_per_lane);
     c->sym_waves = waves;
     c->sym_bpl = bodies_per_lane;
     return NBODY_OK;
@@ -1051,10 +1056,13 @@ int nbody_step_f64(nbody_ctx* c, nbody_double4* d_bodies, nbody_double4* d_accel
     q.n = n;
     q.dt = dt;
     // the symmetric rotation kernel in double (FAST from 16384 bodies, or SYMMETRIC): shapes (waves, bodies per lane)
-    static const int cand[][2] = {{4, 8}, {2, 4}, {1, 2}};
+    // (4,6) measured best at N=262144 (26.4 ms/step; (4,8) 27.1 with 256 VGPR + 23 AGPR and one wave per SIMD, (4,4) 27.2,
+    // (2,6) 26.8); (4,8) stays selectable through nbody_ctx_set_symmetric_shape
+    static const int cand[][2] = {{4, 6}, {2, 4}, {1, 2}, {4, 8}};
     if (c->kernel == NBODY_KERNEL_SYMMETRIC || (c->kernel == NBODY_KERNEL_FAST && n >= kSymMinAuto)) {
         int pick = -1;
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < 4; ++k) {
+            if (k == 3 && !(c->sym_waves == 4 && c->sym_bpl == 8)) continue;  // only on request
             if ((c->sym_waves && cand[k][0] != c->sym_waves) || (c->sym_bpl && cand[k][1] != c->sym_bpl)) continue;
             pick = k;
             if ((long)n >= 128L * 64 * cand[k][0] * cand[k][1]) break;
@@ -1079,6 +1087,7 @@ int nbody_step_f64(nbody_ctx* c, nbody_double4* d_bodies, nbody_double4* d_accel
                     if (int rc = time_mark(c)) return rc;
                     switch (W * 100 + BPL) {
                         case 408: nbk::force_sym<nbk::SymF64<8>, 4><<<grid, 256, 0, c->stream>>>(sp); break;
+                        case 406: nbk::force_sym<nbk::SymF64<6>, 4><<<grid, 256, 0, c->stream>>>(sp); break;
                         case 204: nbk::force_sym<nbk::SymF64<4>, 2><<<grid, 128, 0, c->stream>>>(sp); break;
                         default: nbk::force_sym<nbk::SymF64<2>, 1><<<grid, 64, 0, c->stream>>>(sp); break;
                     }

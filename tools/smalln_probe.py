@@ -9,7 +9,9 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nbody_amd  # noqa: E402
 
-SHAPES = [(1, 2), (1, 4), (2, 4), (1, 8), (2, 8), (4, 8)]
+SHAPES = [(1, 2), (1, 4), (2, 4), (1, 8), (2, 8), (2, 10), (2, 12), (4, 8), (4, 10)]
+if os.environ.get("PROBE_SHAPES"):
+    SHAPES = [tuple(int(t) for t in sh.split("x")) for sh in os.environ["PROBE_SHAPES"].split(",")]
 sizes = [int(a) for a in sys.argv[1:]] or [2048, 4096, 8192, 16384, 32768, 65536, 131072]
 for n in sizes:
     x0 = nbody_amd.engine.seeded_bodies(n, 1, 1)
