@@ -174,14 +174,13 @@ int main(int argc, char** argv)
     printf("N=%d %s  one-sided vs fp64 truth: %.3g of max|a|\n", n, plummer ? "plummer" : "cube", err_vs_truth(a_ref));
 
     std::vector<SymVariant> vars;
-    vars.push_back(sym_variant<nbk::SymPacked<8>, 4>("sym packed bpl8 w4 (B=2048)"));
-    vars.push_back(sym_variant<nbk::SymPacked<6>, 4>("sym packed bpl6 w4 (B=1536)"));
     vars.push_back(sym_variant<nbk::SymPacked<10>, 4>("sym packed bpl10 w4 (B=2560)"));
-    vars.push_back(sym_variant<nbk::SymPacked<12>, 4>("sym packed bpl12 w4 (B=3072)"));
-    vars.push_back(sym_variant<nbk::SymPacked<8>, 2>("sym packed bpl8 w2 (B=1024)"));
-    vars.push_back(sym_variant<nbk::SymPacked<10>, 2>("sym packed bpl10 w2 (B=1280)"));
-    vars.push_back(sym_variant<nbk::SymPacked<12>, 2>("sym packed bpl12 w2 (B=1536)"));
-    vars.push_back(sym_variant<nbk::SymPacked<8>, 4>("sym packed bpl8 w4 (B=2048) again"));
+    vars.push_back(sym_variant<nbk::SymPacked<10>, 4, 3>("sym packed bpl10 w4 minw3 (B=2560)"));
+    vars.push_back(sym_variant<nbk::SymPacked<10>, 3>("sym packed bpl10 w3 (B=1920)"));
+    vars.push_back(sym_variant<nbk::SymPacked<10>, 5>("sym packed bpl10 w5 (B=3200)"));
+    vars.push_back(sym_variant<nbk::SymPacked<10>, 8>("sym packed bpl10 w8 (B=5120)"));
+    vars.push_back(sym_variant<nbk::SymPacked<8>, 4>("sym packed bpl8 w4 (B=2048)"));
+    vars.push_back(sym_variant<nbk::SymPacked<10>, 4>("sym packed bpl10 w4 (B=2560) again"));
     const double pairs = (double)n * n;
     const float t_ref = median_ms(one_sided, reps);
     printf("%-34s %8.3f ms  %.3e pairs/s  %.1f%% of 157.3 TF\n", "one-sided lds packed bpl4 t2048", t_ref, pairs / t_ref * 1e3,
