@@ -17,6 +17,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--bodies", type=int, default=1048576)
 ap.add_argument("--kernel", default="fast")
 ap.add_argument("--steps", type=int, default=6)
+ap.add_argument("--sym-waves", type=int, default=0)
+ap.add_argument("--sym-bpl", type=int, default=0)
 ap.add_argument("worlds", type=int, nargs="*", default=[1, 2, 4, 8])
 args = ap.parse_args()
 L, lib = nbody_amd._lib, nbody_amd.load()
@@ -25,6 +27,8 @@ kernel = {"fast": nbody_amd.KERNEL_FAST, "onesided": nbody_amd.KERNEL_ONESIDED}[
 for G in args.worlds:
     rank = G // 2
     ctx = nbody_amd.engine.Context(dt=0.01, kernel=kernel)
+    if args.sym_waves or args.sym_bpl:
+        ctx.set_symmetric_shape(args.sym_waves, args.sym_bpl)
     g = L.ALL_GATHER_FN(lambda *a: 0)
     e = L.EXCHANGE_FN(lambda *a: 0)
     comm = L.Comm(None, g, e)
