@@ -120,7 +120,7 @@ int nbody_ctx_set_kernel(nbody_ctx* ctx, int kernel, int tile, int bodies_per_la
 
 /* Shape of the symmetric kernel: wave64s per workgroup and stationary bodies per lane; a block is
  * 64*waves*bodies_per_lane bodies. Built: (4,10) (4,8) (2,10) (2,8) (1,8) (2,4) (1,4) (1,2); 0 = auto (the
- * largest block that still gives 72 blocks). The fp64 step takes (4,6) (4,8) (2,4) (1,2). */
+ * cheapest by the library's cost estimate, see nbody_plan_symmetric). The fp64 step takes (4,6) (4,8) (2,4) (1,2). */
 int nbody_ctx_set_symmetric_shape(nbody_ctx* ctx, int waves, int bodies_per_lane);
 
 /* Launch on this HIP stream (a hipStream_t passed as void*; NULL = the context's own stream). */
@@ -360,6 +360,12 @@ int nbody_ctx_step_info(nbody_ctx* ctx, int n, int* symmetric, int* block_bodies
  * launcher would pick. blocks_x = workgroups along the targets; the grid is blocks_x * jsplit. */
 int nbody_plan(int n_targets, int n_sources, int kernel, int tile, int bodies_per_lane, int jsplit,
                int num_cu, int* out_bodies_per_lane, int* out_tile, int* out_jsplit, int* out_blocks_x);
+
+/* The symmetric kernel's block-shape choice for n bodies without a context or a device: waves / bodies_per_lane = 0 leave
+ * the choice to the library (cheapest by its cost estimate: per-step instruction costs, waves per SIMD, the last partial
+ * round, the slab sum), non-zero values restrict it. blocks = slabs per body, workgroups = grid size. */
+int nbody_plan_symmetric(int n, int num_cu, int waves, int bodies_per_lane, int* out_waves, int* out_bodies_per_lane,
+                         int* out_blocks, int* out_workgroups);
 
 #ifdef __cplusplus
 }

@@ -203,21 +203,40 @@ constexpr int kSymMaxSlabs = 2048;
 constexpr size_t kSymMaxWorkspace = (size_t)96 << 30;  // one slab per block: beyond 96 GiB of partial sums the one-sided kernel takes over
 
 // (waves, bodies per lane) instantiated below, largest block first
-const int kSymCand[][2] = {{4, 10}, {4, 8}, {2, 10}, {2, 8}, {1, 8}, {2, 4}, {1, 4}, {1, 2}};
-constexpr int kSymCands = 8;
+const int kSymCand[][2] = {{4, 10}, {4, 8}, {2, 10}, {2, 8}, {1, 10}, {1, 8}, {2, 4}, {1, 4}, {1, 2}};
+constexpr int kSymCands = 9;
+
+// Estimated time (shader cycles) of one launch of `tasks` equal block-pair tasks of shape (W waves, bpl bodies per lane) plus
+// the cost of summing `slab_bytes` of partial sums afterwards. The kernel is VALU-bound with two or more waves on a SIMD, so a
+// SIMD's time is the number of wave-tasks it hosts times the time of one alone: full rounds put `wps` waves on every SIMD
+// (wps from the kernel's VGPR allocation), the last partial round ceil(rest * W / SIMDs). One wave-task = B steps of
+// (41.33 * bpl + 22.6) cycles — 8 bpl/2 packed ops at 4.15, bpl v_rsq_f32 at 8.13, 10 per-step instructions at 2.26
+// (tools/valu_mb.hip). Checked against tools/smalln_probe.py sweeps from 32768 to 1048576 bodies
+// (profiles/r02_shape_probe_{mid,large}.jsonl): it ranks the shapes as measured at every size.
+double sym_cost(int W, int bpl, long tasks, double slab_bytes, int num_cu)
+{
+    const int wps = bpl >= 10 ? 2 : bpl >= 8 ? 3 : bpl >= 4 ? 5 : 8;      // waves per SIMD the VGPR count allows
+    const long simds = 4L * num_cu;
+    const long slots = simds * wps / W;                                     // resident workgroups
+    const long full = tasks / slots, rest = tasks - full * slots;
+    const double deep = (double)full * wps + (double)((rest * W + simds - 1) / simds);
+    const double step = 41.33 * bpl + 22.6;
+    const double B = 64.0 * W * bpl;
+    return B * step * deep + slab_bytes / 4.7e12 * 2.26e9;                   // slab sum at 4.7 TB/s, 2.26 GHz
+}
 
 bool sym_resolve(const nbody_ctx* c, int n, SymShape* out)
 {
     int pick = -1;
+    double best = 0.0;
     for (int k = 0; k < kSymCands; ++k) {
         if ((c->sym_waves && kSymCand[k][0] != c->sym_waves) || (c->sym_bpl && kSymCand[k][1] != c->sym_bpl)) continue;
-        pick = k;
-        // the first shape of the list (largest block first) that still gives 72 blocks: measured best or within 0.5 % of the
-        // best at every size from 16384 to 1048576 bodies (tools/smalln_probe.py, profiles/r02_smalln_probe_{a,b}.jsonl,
-        // profiles/r02_shape_probe_large.jsonl): 10 bodies per lane and 2560-body blocks from 196608 bodies (+2.6 % over 8
-        // per lane at 262144), 1280-body blocks around 100k, single-wave 512-body blocks at 65536; with fewer blocks the
-        // tasks fall unevenly on the SIMDs and the fullest ones set the kernel time
-        if ((long)n >= 72L * 64 * kSymCand[k][0] * kSymCand[k][1]) break;
+        const long B = 64L * kSymCand[k][0] * kSymCand[k][1];
+        const long nb = (n + B - 1) / B;
+        if (nb < 2 && pick >= 0) continue;
+        if (nb > kSymMaxSlabs || (size_t)nb * (size_t)n * sizeof(float4) > kSymMaxWorkspace) continue;
+        const double cost = sym_cost(kSymCand[k][0], kSymCand[k][1], nb * (nb + 1) / 2, (double)nb * n * sizeof(float4), c->num_cu);
+        if (pick < 0 || cost < best) { pick = k; best = cost; }
     }
     if (pick < 0) return false;
     SymShape y{};
@@ -248,16 +267,19 @@ void sym_square_params(nbk::SymParams* sp, const float4* x, int i0, int n, const
     sp->eps2 = eps2;
 }
 
-// Block shape for the symmetric evaluation of TWO disjoint ranges (ni x nj bodies): the largest block that
-// still gives about eight workgroups per CU.
+// Block shape for the symmetric evaluation of TWO disjoint ranges (ni x nj bodies): the cheapest by the same estimate
+// (padding of both sides to whole blocks included through the task count).
 bool sym_resolve_cross(const nbody_ctx* c, int ni, int nj, SymShape* out, int* nbj)
 {
     int pick = -1;
+    double best = 0.0;
     for (int k = 0; k < kSymCands; ++k) {
         if ((c->sym_waves && kSymCand[k][0] != c->sym_waves) || (c->sym_bpl && kSymCand[k][1] != c->sym_bpl)) continue;
-        pick = k;
         const long B = 64L * kSymCand[k][0] * kSymCand[k][1];
-        if (((ni + B - 1) / B) * ((nj + B - 1) / B) >= 8L * c->num_cu) break;
+        const long bi = (ni + B - 1) / B, bj = (nj + B - 1) / B;
+        if (bi > kSymMaxSlabs || bj > 4 * kSymMaxSlabs) continue;
+        const double cost = sym_cost(kSymCand[k][0], kSymCand[k][1], bi * bj, ((double)bj * ni + (double)bi * nj) * sizeof(float4), c->num_cu);
+        if (pick < 0 || cost < best) { pick = k; best = cost; }
     }
     if (pick < 0) return false;
     SymShape y{};
@@ -267,7 +289,6 @@ bool sym_resolve_cross(const nbody_ctx* c, int ni, int nj, SymShape* out, int* n
     y.nb = (ni + y.block - 1) / y.block;
     const int bj = (nj + y.block - 1) / y.block;
     y.grid = y.nb * bj;
-    if (y.nb > kSymMaxSlabs || bj > 4 * kSymMaxSlabs) return false;
     *out = y;
     *nbj = bj;
     return true;
@@ -378,6 +399,7 @@ int launch_sym_untimed(nbody_ctx* c, const SymShape& y0, const nbk::SymParams& p
         case 408: nbk::force_sym<SymPacked<8>, 4><<<y.grid, 256, 0, c->stream>>>(p); break;
         case 210: nbk::force_sym<SymPacked<10>, 2><<<y.grid, 128, 0, c->stream>>>(p); break;
         case 208: nbk::force_sym<SymPacked<8>, 2><<<y.grid, 128, 0, c->stream>>>(p); break;
+        case 110: nbk::force_sym<SymPacked<10>, 1><<<y.grid, 64, 0, c->stream>>>(p); break;
         case 108: nbk::force_sym<SymPacked<8>, 1><<<y.grid, 64, 0, c->stream>>>(p); break;
         case 204: nbk::force_sym<SymPacked<4>, 2><<<y.grid, 128, 0, c->stream>>>(p); break;
         case 104: nbk::force_sym<SymPacked<4>, 1><<<y.grid, 64, 0, c->stream>>>(p); break;
@@ -580,6 +602,25 @@ int nbody_plan(int n_targets, int n_sources, int kernel, int tile, int bodies_pe
     if (out_tile) *out_tile = s.tile;
     if (out_jsplit) *out_jsplit = s.jsplit;
     if (out_blocks_x) *out_blocks_x = s.blocks_x;
+    return NBODY_OK;
+}
+
+// Device-free view of the symmetric kernel's shape choice.
+int nbody_plan_symmetric(int n, int num_cu, int waves, int bodies_per_lane, int* out_waves, int* out_bodies_per_lane,
+                         int* out_blocks, int* out_workgroups)
+{
+    if (n < 0 || num_cu <= 0) return fail(NBODY_ERR_INVALID, "bad plan arguments");
+    nbody_ctx tmp;
+    tmp.kernel = NBODY_KERNEL_SYMMETRIC;
+    tmp.sym_waves = waves;
+    tmp.sym_bpl = bodies_per_lane;
+    tmp.num_cu = num_cu;
+    SymShape y{};
+    if (!sym_resolve(&tmp, n, &y)) return fail(NBODY_ERR_CONFIG, "no symmetric shape for %d bodies (waves=%d, bodies_per_lane=%d)", n, waves, bodies_per_lane);
+    if (out_waves) *out_waves = y.waves;
+    if (out_bodies_per_lane) *out_bodies_per_lane = y.bpl;
+    if (out_blocks) *out_blocks = y.nb;
+    if (out_workgroups) *out_workgroups = y.grid;
     return NBODY_OK;
 }
 

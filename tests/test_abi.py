@@ -149,3 +149,28 @@ def test_bench_defaults_name_the_baseline_configs():
         assert b.default_workload(g, 0, "strong") == (1048576, "strong")
     assert b.default_workload(8, 0, "weak") == (720896, "weak")
     assert b.default_workload(4, 65536, "strong") == (65536, "strong")
+
+
+def test_symmetric_shape_choice_without_a_device():
+    """nbody_plan_symmetric: the block shape the cost estimate picks at the sizes the sweeps were measured at
+    (profiles/r02_shape_probe_{mid,large}.jsonl: the measured best at each), and how restrictions narrow it."""
+    import nbody_amd as nb
+    lib = nb.load()
+
+    def plan(n, waves=0, bpl=0, cus=256):
+        o = [C.c_int() for _ in range(4)]
+        rc = lib.nbody_plan_symmetric(n, cus, waves, bpl, *[C.byref(x) for x in o])
+        return rc, tuple(x.value for x in o)
+
+    assert plan(262144) == (0, (4, 10, 103, 5356))            # BASELINE configs[2]
+    assert plan(1048576) == (0, (4, 10, 410, 84255))          # configs[3] on one GPU
+    assert plan(65536)[1][:2] == (1, 8)                       # configs[1]
+    assert plan(32768)[1][:2] == (1, 4) and plan(98304)[1][:2] == (2, 10) and plan(16384)[1][:2] == (1, 2)
+    assert plan(8192) == (0, (1, 2, 64, 2080))                # the reference's N_BODIES, when the symmetric kernel is forced
+    assert plan(262144, 4, 8) == (0, (4, 8, 128, 8256)) and plan(262144, 0, 8)[1][1] == 8
+    for n in (130, 1000, 5000, 100003, 3000000):
+        rc, (w, b, blocks, wgs) = plan(n)
+        assert rc == 0 and blocks == -(-n // (64 * w * b)) and blocks >= 2 and wgs == blocks * (blocks + 1) // 2
+    assert plan(100)[0] != 0                                  # one block: nothing to pair up
+    assert plan(262144, 3, 8)[0] != 0 and plan(-1)[0] != 0 and plan(1000, cus=0)[0] != 0
+    assert plan(40_000_000)[0] != 0                           # beyond the 96 GiB slab cap: the one-sided kernel takes over
