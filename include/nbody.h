@@ -119,7 +119,7 @@ int nbody_ctx_set_params(nbody_ctx* ctx, float dt, float eps2);
 int nbody_ctx_set_kernel(nbody_ctx* ctx, int kernel, int tile, int bodies_per_lane, int jsplit);
 
 /* Shape of the symmetric kernel: wave64s per workgroup and stationary bodies per lane; a block is
- * 64*waves*bodies_per_lane bodies. Built: (4,10) (4,8) (2,10) (2,8) (1,8) (2,4) (1,4) (1,2); 0 = auto (the
+ * 64*waves*bodies_per_lane bodies. Built: (4,10) (4,8) (2,10) (2,8) (1,10) (1,8) (2,4) (1,4) (1,2); 0 = auto (the
  * cheapest by the library's cost estimate, see nbody_plan_symmetric). The fp64 step takes (4,6) (4,8) (2,4) (1,2). */
 int nbody_ctx_set_symmetric_shape(nbody_ctx* ctx, int waves, int bodies_per_lane);
 

@@ -561,7 +561,7 @@ int nbody_ctx_set_symmetric_shape(nbody_ctx* c, int waves, int bodies_per_lane)
         ok = (waves == 0 || waves == kSymCand[k][0]) && (bodies_per_lane == 0 || bodies_per_lane == kSymCand[k][1]);
     if (waves == 4 && bodies_per_lane == 6) ok = true;  // fp64 only
     if (!ok)
-        return fail(NBODY_ERR_CONFIG, "symmetric kernel is built for (waves, bodies_per_lane) in {(4,10),(4,8),(2,10),(2,8),(1,8),(2,4),(1,4),(1,2)} "
+        return fail(NBODY_ERR_CONFIG, "symmetric kernel is built for (waves, bodies_per_lane) in {(4,10),(4,8),(2,10),(2,8),(1,10),(1,8),(2,4),(1,4),(1,2)} "
                     "(fp64: (4,6),(4,8),(2,4),(1,2)); got (%d,%d)", waves, bodies_per_lane);
     c->sym_waves = waves;
     c->sym_bpl = bodies_per_lane;

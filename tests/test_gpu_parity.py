@@ -115,7 +115,7 @@ def test_fast_kernel_configurations_agree(nb, oracle, opts):
 
 # ---- the symmetric kernel (every unordered pair once) -----------------------------------------------
 
-@pytest.mark.parametrize("waves,bpl", [(1, 2), (1, 4), (2, 4), (1, 8), (2, 8), (2, 10), (4, 8), (4, 10)])
+@pytest.mark.parametrize("waves,bpl", [(1, 2), (1, 4), (2, 4), (1, 8), (1, 10), (2, 8), (2, 10), (4, 8), (4, 10)])
 @pytest.mark.parametrize("n,init", [(1000, 0), (4099, 1), (6144, 0)])
 def test_symmetric_kernel_shapes_vs_oracle(nb, oracle, waves, bpl, n, init):
     """Every block shape the library builds, on sizes that are not multiples of the block (the last
@@ -241,7 +241,7 @@ def test_randomised_symmetric_and_cross_cases(nb, oracle):
     coincident bodies: the symmetric kernel over the whole set, and nbody_accel_cross over a random split of it, against
     the fp64-accumulated CPU sums; the two sides of every cross call balance (sum of m*a over both sets = 0)."""
     rng = np.random.default_rng(2718)
-    shapes = [(1, 2), (1, 4), (2, 4), (1, 8), (2, 8), (2, 10), (4, 8), (4, 10)]
+    shapes = [(1, 2), (1, 4), (2, 4), (1, 8), (1, 10), (2, 8), (2, 10), (4, 8), (4, 10)]
     for case in range(30):
         w, b = shapes[case % len(shapes)]
         n = int(rng.integers(2 * 64 * w * b, 2 * 64 * w * b + 3000))
