@@ -584,9 +584,9 @@ def test_config5_f64_at_n262144(nb, oracle):
 
 # ---- hipGraph replay of launch-bound steps ---------------------------------------------------------------
 
-@pytest.mark.parametrize("n,kernel", [(4096, "fast"), (1000, "fast"), (2048, "strict")])
+@pytest.mark.parametrize("n,kernel", [(4096, "fast"), (1000, "fast"), (2048, "strict"), (4096, "symmetric")])
 def test_graph_replay_is_identical_to_eager_launches(nb, n, kernel):
-    k = nb.KERNEL_FAST if kernel == "fast" else nb.KERNEL_STRICT
+    k = {"fast": nb.KERNEL_FAST, "strict": nb.KERNEL_STRICT, "symmetric": nb.KERNEL_SYMMETRIC}[kernel]
     x0 = nb.engine.seeded_bodies(n, 1, 3)
     out = []
     for mode in (0, 1):
