@@ -622,7 +622,7 @@ __global__ void __launch_bounds__(64 * W, MINW) force_sym(const SymParamsT<typen
 
     if (!diag) {
 #pragma unroll
-        for (int e = tid; e < B; e += 64 * W) sh[e] = zero4<V4>();
+        for (int r = 0; r < BPL; ++r) sh[r * (64 * W) + tid] = zero4<V4>();  // B = BPL * 64*W
         __syncthreads();
     }
     int c = w * BPL;  // chunk of this wave in round 0 (distinct per wave, NCH = W*BPL chunks)
