@@ -10,6 +10,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -435,9 +436,11 @@ struct RcclApi {
 };
 
 RcclApi g_rccl;
+std::mutex g_rccl_mu;  // ranks may be threads of one process (nbody_headless --ngpu): load the library once
 
 int rccl_load()
 {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
     if (g_rccl.handle) return NBODY_OK;
     void* h = nullptr;
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
