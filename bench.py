@@ -233,7 +233,7 @@ def main():
         ctx = sim.ctx
         run = lambda k: sim.run(k)
         sync = ctx.sync
-        sym64 = kernel != nbody_amd.KERNEL_ONESIDED and (n >= 16384 or kernel == nbody_amd.KERNEL_SYMMETRIC)
+        sym64 = kernel != nbody_amd.KERNEL_ONESIDED and (n >= 12288 or kernel == nbody_amd.KERNEL_SYMMETRIC)
         info = {"symmetric": sym64, "slabs": args.jsplit or "auto", "evaluated_pairs": float(n) * n}
         if sym64:   # the double-precision rotation kernel: blocks of 64*waves*bpl bodies, each unordered pair once
             cands = [(4, 6), (2, 4), (1, 2)]

@@ -61,7 +61,7 @@ enum {
 /* Arithmetic flavour of the force kernel. */
 enum {
     NBODY_KERNEL_FAST = 0,      /* packed fp32, v_rsq_f32, fma; tolerance-level parity. A whole step (or a  */
-                                /* square block of nbody_accel_range) of >= 16384 bodies runs the SYMMETRIC */
+                                /* square block of nbody_accel_range) of >= 12288 bodies runs the SYMMETRIC */
                                 /* kernel, anything else the ONESIDED one                                   */
     NBODY_KERNEL_STRICT = 1,    /* the reference's operation order with IEEE sqrt/div, no fma contraction,  */
                                 /* j==i skipped: bit-identical to validation.cpp's arithmetic taken in      */
@@ -122,6 +122,12 @@ int nbody_ctx_set_kernel(nbody_ctx* ctx, int kernel, int tile, int bodies_per_la
  * 64*waves*bodies_per_lane bodies. Built: (4,10) (4,8) (2,10) (2,8) (1,10) (1,8) (2,4) (1,4) (1,2); 0 = auto (the
  * cheapest by the library's cost estimate, see nbody_plan_symmetric). The fp64 step takes (4,6) (4,8) (2,4) (1,2). */
 int nbody_ctx_set_symmetric_shape(nbody_ctx* ctx, int waves, int bodies_per_lane);
+
+/* The symmetric kernel has a second decomposition for mid-size systems (about 16k ... 128k bodies), where whole block
+ * pairs are too coarse a unit for 1024 SIMDs: independent waves take RUNS of (I-block, one 64-body chunk) units. mode -1
+ * (default): used where the library's cost estimate prefers it (never when a waves count was set through
+ * nbody_ctx_set_symmetric_shape); 0: never; 1: always (bodies_per_lane 8 or 10). Same arithmetic, same determinism. */
+int nbody_ctx_set_symmetric_runs(nbody_ctx* ctx, int mode);
 
 /* Launch on this HIP stream (a hipStream_t passed as void*; NULL = the context's own stream). */
 int nbody_ctx_set_stream(nbody_ctx* ctx, void* hip_stream);
@@ -348,7 +354,8 @@ const char* nbody_version(void);
 int nbody_ctx_launch_info(nbody_ctx* ctx, int n_targets, int n_sources, int* jsplit, int* blocks,
                           int* lds_bytes);
 
-/* What nbody_step() does for n bodies: symmetric = 1 when the symmetric kernel runs; block_bodies = bodies
+/* What nbody_step() does for n bodies: symmetric = 1 when the symmetric kernel runs on block pairs, 2 when it runs in
+ * runs of chunk units, 0 for the one-sided kernel; block_bodies = bodies
  * per block (symmetric) or per workgroup (one-sided); slabs = partial-sum slabs the integrate adds;
  * workgroups = grid size; evaluated_pairs = pair evaluations per step (n*n one-sided; about n*n/2 plus
  * the diagonal blocks symmetric — the interactions applied are n*n either way). Any out pointer may be NULL. */

@@ -18,7 +18,7 @@ ERR_HIP = 2
 ERR_CONFIG = 3
 ERR_NOMEM = 4
 
-KERNEL_FAST = 0       # symmetric kernel for whole steps / square blocks of >= 16384 bodies, else one-sided
+KERNEL_FAST = 0       # symmetric kernel for whole steps / square blocks of >= 12288 bodies, else one-sided
 KERNEL_STRICT = 1
 KERNEL_ONESIDED = 2   # fast arithmetic, every target evaluates all N sources
 KERNEL_SYMMETRIC = 3  # fast arithmetic, every unordered pair once (Newton's third law)
@@ -78,6 +78,7 @@ _SIGNATURES = {
     "nbody_ctx_set_params": (C.c_int, [_p, C.c_float, C.c_float]),
     "nbody_ctx_set_kernel": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "nbody_ctx_set_symmetric_shape": (C.c_int, [_p, C.c_int, C.c_int]),
+    "nbody_ctx_set_symmetric_runs": (C.c_int, [_p, C.c_int]),
     "nbody_ctx_set_stream": (C.c_int, [_p, _p]),
     "nbody_ctx_reserve": (C.c_int, [_p, C.c_int]),
     "nbody_ctx_set_graph": (C.c_int, [_p, C.c_int]),

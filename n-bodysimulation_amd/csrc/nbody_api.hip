@@ -92,6 +92,7 @@ struct nbody_ctx {
     int jsplit = 0;  // 0 = auto
     int sym_waves = 0;  // symmetric kernel: waves per workgroup (0 = auto)
     int sym_bpl = 0;    // symmetric kernel: stationary bodies per lane (0 = auto)
+    int sym_runs = -1;  // run-based variant of the symmetric kernel: -1 where the cost estimate prefers it, 0 never, 1 always
     int num_cu = 256;
     void* slabs = nullptr;     // workspace: jsplit slabs of n_targets float4 (or double4)
     size_t slab_bytes = 0;
@@ -198,7 +199,8 @@ struct SymShape {
     int waves, bpl, block, nb, grid;
 };
 
-constexpr int kSymMinAuto = 16384;  // FAST switches to the symmetric kernel from this many bodies
+constexpr int kSymMinAuto = 12288;  // FAST switches to the symmetric kernel from this many bodies
+constexpr int kRunsMaxAuto = 160000; // the run-based variant is chosen automatically up to this many bodies
 constexpr int kSymMaxSlabs = 2048;
 constexpr size_t kSymMaxWorkspace = (size_t)96 << 30;  // one slab per block: beyond 96 GiB of partial sums the one-sided kernel takes over
 
@@ -292,6 +294,73 @@ bool sym_resolve_cross(const nbody_ctx* c, int ni, int nj, SymShape* out, int* n
     *out = y;
     *nbj = bj;
     return true;
+}
+
+// The run-based variant (nbk::force_sym_run): independent waves, units of one 64-body chunk, L units per worker.
+struct RunShape {
+    int bpl, nbi, nworkers, max_slabs;
+    long nunits;
+    nbk::RunLayout layout;
+};
+
+bool run_resolve(const nbody_ctx* c, int n, RunShape* out, double* cost_out)
+{
+    if (n < 128) return false;
+    int pick = -1;
+    double best = 0.0;
+    RunShape cand[2];
+    static const int bpls[2] = {10, 8};
+    for (int k = 0; k < 2; ++k) {
+        const int bpl = bpls[k];
+        if (c->sym_bpl && c->sym_bpl != bpl) continue;
+        // measured: 10 bodies per lane is the better run shape below 49152 bodies, 8 (three waves per SIMD) from there
+        if (!c->sym_bpl && bpl != (n < 49152 ? 10 : 8)) continue;
+        RunShape y{};
+        y.bpl = bpl;
+        y.layout.bi = 64 * bpl;
+        y.layout.bpl = bpl;
+        y.layout.ncht = (n + 63) / 64;
+        y.nbi = (n + y.layout.bi - 1) / y.layout.bi;
+        y.layout.L = 1;
+        y.nunits = nbk::run_prefix(y.nbi, y.layout);
+        const int wps = bpl >= 10 ? 2 : 3;
+        const long simds = 4L * c->num_cu, slots = simds * wps;
+        long L = (y.nunits + slots - 1) / slots;   // every worker resident at once
+        if (L < 1) L = 1;
+        y.layout.L = (int)L;
+        y.nworkers = (int)((y.nunits + L - 1) / L);
+        y.max_slabs = y.nbi + (int)((y.layout.ncht + L - 1) / L) + 2;
+        if ((size_t)y.max_slabs * (size_t)n * sizeof(float4) > kSymMaxWorkspace) continue;
+        const double unit = 64.0 * (41.33 * bpl + 22.6);
+        const double deep = (double)((y.nworkers + simds - 1) / simds) * (double)L;          // units on the fullest SIMD
+        const double slabs_avg = 0.5 * y.nbi + 0.5 * (double)y.layout.ncht / (double)L + 1.0;
+        const double cost = deep * unit + 6000.0 * (double)((y.nworkers + simds - 1) / simds)  // + per-worker prologue
+                            + slabs_avg * n * sizeof(float4) / 4.7e12 * 2.26e9;
+        cand[k] = y;
+        if (pick < 0 || cost < best) { pick = k; best = cost; }
+    }
+    if (pick < 0) return false;
+    *out = cand[pick];
+    if (cost_out) *cost_out = best;
+    return true;
+}
+
+// Does a square problem of n bodies go to the run-based variant rather than to block pairs?
+bool run_wanted(const nbody_ctx* c, int n, RunShape* out)
+{
+    if (c->sym_runs == 0 || c->sym_waves != 0) return false;
+    if (!(c->kernel == NBODY_KERNEL_SYMMETRIC || (c->kernel == NBODY_KERNEL_FAST && n >= kSymMinAuto))) return false;
+    double rc = 0.0;
+    if (!run_resolve(c, n, out, &rc)) return false;
+    if (c->sym_runs == 1) return true;
+    // Measured (tools/smalln_probe.py, profiles/r02_runs_probe.jsonl, same box): runs beat the best block shape by 3-9 %
+    // from 16384 to 131072 bodies and lose 1 % at 262144 (twice the slabs, single waves); below 12288 the one-sided
+    // kernel wins. The cost estimates of the two decompositions agree with that ordering only inside this range.
+    if (n > kRunsMaxAuto) return false;
+    SymShape y{};         // the block-pair choice it competes with
+    if (!sym_resolve(c, n, &y)) return true;
+    const double bc = sym_cost(y.waves, y.bpl, (long)y.nb * (y.nb + 1) / 2, (double)y.nb * n * sizeof(float4), c->num_cu);
+    return rc < 1.03 * bc;
 }
 
 // Does a square problem of n bodies (targets == sources) go to the symmetric kernel?
@@ -408,6 +477,28 @@ int launch_sym_untimed(nbody_ctx* c, const SymShape& y0, const nbk::SymParams& p
     }
     HIP_TRY(hipGetLastError());
     return NBODY_OK;
+}
+
+int launch_run(nbody_ctx* c, const RunShape& y, const nbk::RunParams& p)
+{
+    if (int rc = time_mark(c)) return rc;
+    if (y.bpl == 10) nbk::force_sym_run<nbk::SymPacked<10>><<<y.nworkers, 64, 0, c->stream>>>(p);
+    else nbk::force_sym_run<nbk::SymPacked<8>><<<y.nworkers, 64, 0, c->stream>>>(p);
+    HIP_TRY(hipGetLastError());
+    return time_mark(c);
+}
+
+void run_params(nbk::RunParams* rp, const float4* x, int n, const RunShape& y, float4* slabs, float eps2)
+{
+    *rp = nbk::RunParams{};
+    rp->x = x;
+    rp->slabs = slabs;
+    rp->n = n;
+    rp->stride = n;
+    rp->nbi = y.nbi;
+    rp->nunits = y.nunits;
+    rp->r = y.layout;
+    rp->eps2 = eps2;
 }
 
 int launch_sym(nbody_ctx* c, const SymShape& y, const nbk::SymParams& p, int ntasks = -1)
@@ -568,6 +659,14 @@ int nbody_ctx_set_symmetric_shape(nbody_ctx* c, int waves, int bodies_per_lane)
     return NBODY_OK;
 }
 
+int nbody_ctx_set_symmetric_runs(nbody_ctx* c, int mode)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (mode < -1 || mode > 1) return fail(NBODY_ERR_CONFIG, "runs mode must be -1 (auto), 0 (never) or 1 (always)");
+    c->sym_runs = mode;
+    return NBODY_OK;
+}
+
 int nbody_ctx_set_stream(nbody_ctx* c, void* hip_stream)
 {
     if (int rc = check_ctx(c)) return rc;
@@ -581,8 +680,10 @@ int nbody_ctx_reserve(nbody_ctx* c, int n_targets)
     if (n_targets < 0) return fail(NBODY_ERR_INVALID, "n_targets < 0");
     ON_DEVICE(c);
     SymShape y{};
+    RunShape ry{};
     size_t slabs = (size_t)resolve_shape(c, n_targets, n_targets).jsplit;
     if (sym_wanted(c, n_targets, &y) && (size_t)y.nb > slabs) slabs = (size_t)y.nb;
+    if (run_wanted(c, n_targets, &ry) && (size_t)ry.max_slabs > slabs) slabs = (size_t)ry.max_slabs;
     return ensure_slabs(c, slabs * (size_t)n_targets * sizeof(float4));
 }
 
@@ -629,6 +730,13 @@ int nbody_ctx_launch_info(nbody_ctx* c, int n_targets, int n_sources, int* jspli
     if (int rc = check_ctx(c)) return rc;
     if (n_targets < 0 || n_sources < 0) return fail(NBODY_ERR_INVALID, "negative size");
     SymShape y{};
+    RunShape ry{};
+    if (n_targets == n_sources && run_wanted(c, n_targets, &ry)) {
+        if (jsplit) *jsplit = ry.max_slabs;
+        if (blocks) *blocks = ry.nworkers;
+        if (lds_bytes) *lds_bytes = 0;
+        return NBODY_OK;
+    }
     if (n_targets == n_sources && sym_wanted(c, n_targets, &y)) {
         if (jsplit) *jsplit = y.nb;
         if (blocks) *blocks = y.grid;
@@ -648,6 +756,15 @@ int nbody_ctx_step_info(nbody_ctx* c, int n, int* symmetric, int* block_bodies, 
     if (int rc = check_ctx(c)) return rc;
     if (n < 0) return fail(NBODY_ERR_INVALID, "negative size");
     SymShape y{};
+    RunShape ry{};
+    if (run_wanted(c, n, &ry)) {
+        if (symmetric) *symmetric = 2;  // symmetric, in runs of chunk units
+        if (block_bodies) *block_bodies = ry.layout.bi;
+        if (slabs) *slabs = ry.max_slabs;
+        if (workgroups) *workgroups = ry.nworkers;
+        if (evaluated_pairs) *evaluated_pairs = (double)ry.nunits * ry.layout.bi * 64.0;
+        return NBODY_OK;
+    }
     if (sym_wanted(c, n, &y)) {
         if (symmetric) *symmetric = 1;
         if (block_bodies) *block_bodies = y.block;
@@ -674,6 +791,25 @@ int accel_impl(nbody_ctx* c, const nbody_float4* d_bodies, nbody_float4* d_acc_o
 {
     const int nt = i1 - i0;
     ON_DEVICE(c);
+    RunShape ry{};
+    if (i0 == j0 && i1 == j1 && !wrap && run_wanted(c, nt, &ry)) {
+        // a square block in runs of chunk units (16k ... 128k bodies)
+        if (int rc = ensure_slabs(c, (size_t)ry.max_slabs * nt * sizeof(float4))) return rc;
+        nbk::RunParams rp{};
+        run_params(&rp, reinterpret_cast<const float4*>(d_bodies) + i0, nt, ry, static_cast<float4*>(c->slabs), c->eps2);
+        if (int rc = launch_run(c, ry, rp)) return rc;
+        nbk::ReduceParams r{};
+        r.out = reinterpret_cast<float4*>(d_acc_out);
+        r.slabs = static_cast<const float4*>(c->slabs);
+        r.nslab = 1;
+        r.slab_stride = nt;
+        r.n = nt;
+        r.accumulate = accumulate ? 1 : 0;
+        r.run = ry.layout;
+        nbk::reduce_slabs<<<(nt + nbk::kWG - 1) / nbk::kWG, nbk::kWG, 0, c->stream>>>(r);
+        HIP_TRY(hipGetLastError());
+        return NBODY_OK;
+    }
     SymShape y{};
     if (i0 == j0 && i1 == j1 && sym_wanted(c, nt, &y)) {
         // a square block (targets == sources): every unordered pair once
@@ -747,7 +883,9 @@ int nbody_accel_square_part(nbody_ctx* c, const nbody_float4* d_bodies, nbody_fl
     if (!d_bodies || !d_acc_out) return fail(NBODY_ERR_INVALID, "null device pointer");
     const int nt = i1 - i0;
     SymShape y{};
-    if (!sym_wanted(c, nt, &y))  // no symmetric kernel for this size / kernel id: the first part is the whole evaluation
+    // One part, or no block-pair launch for this size / kernel id: the first part is the whole evaluation. (With several
+    // parts the block-pair decomposition is used even where runs would be a few per cent faster: only a task list splits.)
+    if (nparts == 1 || !sym_wanted(c, nt, &y))
         return part == 0 ? accel_impl(c, d_bodies, d_acc_out, i0, i1, i0, i1, 0, accumulate) : NBODY_OK;
     ON_DEVICE(c);
     if (int rc = ensure_slabs(c, (size_t)y.nb * nt * sizeof(float4))) return rc;
@@ -872,17 +1010,27 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
     if (!d_bodies || !d_accelerations || !d_velocity) return fail(NBODY_ERR_INVALID, "null device pointer");
     ON_DEVICE(c);
     SymShape y{};
-    const bool sym = sym_wanted(c, n, &y);
+    RunShape ry{};
+    const bool runs = run_wanted(c, n, &ry);
+    const bool sym = !runs && sym_wanted(c, n, &y);
     const Shape s = resolve_shape(c, n, n);
     nbk::ForceParams p{};
     nbk::SymParams sp{};
+    nbk::RunParams rp{};
     nbk::IntegrateParams q{};
     q.x = reinterpret_cast<float4*>(d_bodies);
     q.v = reinterpret_cast<float4*>(d_velocity);
     q.a = reinterpret_cast<float4*>(d_accelerations);
     q.n = n;
     q.dt = c->dt;
-    if (sym) {
+    if (runs) {
+        if (int rc = ensure_slabs(c, (size_t)ry.max_slabs * n * sizeof(float4))) return rc;
+        run_params(&rp, reinterpret_cast<const float4*>(d_bodies), n, ry, static_cast<float4*>(c->slabs), c->eps2);
+        q.slabs = static_cast<const float4*>(c->slabs);
+        q.nslab = 1;
+        q.slab_stride = n;
+        q.run = ry.layout;
+    } else if (sym) {
         if (int rc = ensure_slabs(c, (size_t)y.nb * n * sizeof(float4))) return rc;
         sym_square_params(&sp, reinterpret_cast<const float4*>(d_bodies), 0, n, y, static_cast<float4*>(c->slabs), c->eps2);
         q.slabs = static_cast<const float4*>(c->slabs);
@@ -912,7 +1060,8 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
     // one step = one force launch + one integrate launch, both checked
     auto enqueue_step = [&](bool timed) -> int {
         int rc;
-        if (sym) rc = timed ? launch_sym(c, y, sp) : launch_sym_untimed(c, y, sp);
+        if (runs) rc = launch_run(c, ry, rp);
+        else if (sym) rc = timed ? launch_sym(c, y, sp) : launch_sym_untimed(c, y, sp);
         else rc = timed ? launch_force(c, s, p) : launch_force_untimed(c, s, p);
         if (rc != NBODY_OK) return rc;
         nbk::integrate<<<iblocks, nbk::kWG, 0, c->stream>>>(q);
@@ -924,8 +1073,8 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
     if (graphable && steps >= kGraphChunk) {
         // Launch-bound regime: replay a captured chain of kGraphChunk steps instead of 2*kGraphChunk
         // host launches. The kernels and their order are exactly those of the loop below.
-        const nbody_ctx::GraphKey key{d_bodies, q.a, q.v, c->slabs, n, sym ? y.bpl : s.bpl, sym ? y.waves : s.tile,
-                                      sym ? y.nb : s.jsplit, c->kernel, kGraphChunk, c->dt, c->eps2, c->stream};
+        const nbody_ctx::GraphKey key{d_bodies, q.a, q.v, c->slabs, n, runs ? ry.bpl : sym ? y.bpl : s.bpl, runs ? -1 : sym ? y.waves : s.tile,
+                                      runs ? ry.layout.L : sym ? y.nb : s.jsplit, c->kernel, kGraphChunk, c->dt, c->eps2, c->stream};
         if (!c->graph_exec || !(key == c->graph_key)) {
             if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
             if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }

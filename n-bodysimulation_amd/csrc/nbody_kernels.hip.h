@@ -670,6 +670,115 @@ __global__ void __launch_bounds__(64 * W, MINW) force_sym(const SymParamsT<typen
 }
 
 // ---------------------------------------------------------------------------------------
+// symmetric flavour in RUNS — the same pair arithmetic for systems of 16k ... 128k bodies, where whole block pairs are
+// too coarse a unit of work for 1024 SIMDs
+// ---------------------------------------------------------------------------------------
+//
+// One wave is a worker of its own (no LDS, no barrier). The unit of work is (I-block of 64*BPL bodies, ONE chunk of 64
+// J bodies): row I of the unit list holds the chunks from the block's own first chunk to the last chunk of the system
+// (own chunks one-sided, later chunks symmetric), rows are laid end to end, and worker g takes units [g*L, (g+1)*L) — a run
+// that may continue into the next row. Per run and row the worker loads the I-block once, streams its chunks through the
+// register rotation, stores every chunk's J-side sums straight from registers (one float4 per lane) and the I-side sums
+// once at the end. Slabs of body k (I-block K): index I' < K holds the J-side sums from row I', index K + s the I-side
+// sums of the s-th worker that touched row K — indices 0 .. K + nseg(K) - 1, all written, added in index order.
+
+struct RunLayout {
+    int bi;    // bodies per I-block (64*BPL); 0 = not a run layout: a fixed number of slabs
+    int bpl;   // chunks per I-block
+    int ncht;  // chunks of 64 bodies in the system
+    int L;     // units per worker
+};
+
+__host__ __device__ inline long run_prefix(long I, const RunLayout& r) { return I * r.ncht - (long)r.bpl * I * (I - 1) / 2; }
+
+// number of slabs that hold a partial sum of body k
+__host__ __device__ inline int run_slab_count(int k, const RunLayout& r)
+{
+    const long K = k / r.bi;
+    const long first = run_prefix(K, r) / r.L, last = (run_prefix(K + 1, r) - 1) / r.L;
+    return (int)(K + (last - first + 1));
+}
+
+struct RunParams {
+    const float4* x;
+    float4* slabs;
+    int n, stride;
+    int nbi;       // I-blocks
+    long nunits;   // run_prefix(nbi)
+    RunLayout r;
+    float eps2;
+};
+
+template <class M>
+__global__ void __launch_bounds__(64) force_sym_run(const RunParams p)
+{
+    constexpr int BPL = M::BPL;
+    const int lane = threadIdx.x;
+    const long g = blockIdx.x;
+    long u = g * p.r.L;
+    const long u1 = (u + p.r.L < p.nunits) ? u + p.r.L : p.nunits;
+    if (u >= u1) return;
+    // row of the first unit: the largest I with run_prefix(I) <= u
+    int I;
+    {
+        int lo = 0, hi = p.nbi - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (run_prefix(mid, p.r) <= u) lo = mid; else hi = mid - 1;
+        }
+        I = lo;
+    }
+    const int rot = ((lane + 16) & 63) << 2;
+    auto fetch = [&](int c) {
+        const int j = c * 64 + lane;
+        return j < p.n ? p.x[j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    };
+    M t;
+    t.set_eps2(p.eps2);
+    for (; u < u1; ++I) {
+        const long row0 = run_prefix(I, p.r), row1 = run_prefix(I + 1, p.r);
+        const long seg1 = u1 < row1 ? u1 : row1;
+        int c = I * BPL + (int)(u - row0);
+        const int ibase = I * (64 * BPL) + lane;
+#pragma unroll
+        for (int k = 0; k < BPL; ++k) {
+            const int i = ibase + k * 64;
+            t.set(k, i < p.n ? p.x[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        }
+        float4* const out_j = p.slabs + (size_t)I * p.stride;
+        float4 nxt = fetch(c);
+        for (; u < seg1; ++u, ++c) {
+            float4 bj = nxt;
+            if (u + 1 < seg1) nxt = fetch(c + 1);
+            if (c < (I + 1) * BPL) {  // a chunk of the block itself: both orders of every pair occur, one side each
+                float4 aj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                for (int ph = 0; ph < 4; ++ph) {
+                    sym_row_pass<false>(t, bj, aj);
+                    bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot); bj.w = next_row(bj.w, rot);
+                }
+            } else {
+                float4 aj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                for (int ph = 0; ph < 4; ++ph) {
+                    sym_row_pass<true>(t, bj, aj);
+                    bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot); bj.w = next_row(bj.w, rot);
+                    aj.x = next_row(aj.x, rot); aj.y = next_row(aj.y, rot); aj.z = next_row(aj.z, rot);
+                }
+                const int j = c * 64 + lane;  // back in the home lane after four row moves
+                aj.w = 0.0f;
+                if (j < p.n) out_j[j] = aj;
+            }
+        }
+        const int seg = (int)(g - row0 / p.r.L);  // this worker's ordinal among the workers of row I
+        float4* const out_i = p.slabs + (size_t)(I + seg) * p.stride;
+#pragma unroll
+        for (int k = 0; k < BPL; ++k) {
+            const int i = ibase + k * 64;
+            if (i < p.n) out_i[i] = t.acc(k);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // strict flavour — the reference's arithmetic, operation by operation
 // ---------------------------------------------------------------------------------------
 
@@ -744,6 +853,7 @@ struct IntegrateParams {
     int slab_stride;
     int n;                 // own bodies
     float dt;
+    RunLayout run;         // run.bi != 0: body i has run_slab_count(i) slabs instead of nslab
 };
 
 __global__ void __launch_bounds__(kWG) integrate(const IntegrateParams p)
@@ -753,10 +863,11 @@ __global__ void __launch_bounds__(kWG) integrate(const IntegrateParams p)
     if (i >= p.n) return;
     float4 a;
     if (p.nslab > 0) {
+        const int nslab = p.run.bi ? run_slab_count(i, p.run) : p.nslab;
         a = p.slabs[i];
         // the sum is taken in slab order whatever the unrolling: only the loads are batched
 #pragma unroll 8
-        for (int s = 1; s < p.nslab; ++s) {
+        for (int s = 1; s < nslab; ++s) {
             const float4 q = p.slabs[(size_t)s * p.slab_stride + i];
             a.x += q.x; a.y += q.y; a.z += q.z;
         }
@@ -822,6 +933,7 @@ struct ReduceParams {
     int slab_stride;
     int n;
     int accumulate;
+    RunLayout run;  // run.bi != 0: body i has run_slab_count(i) slabs instead of nslab
 };
 
 __global__ void __launch_bounds__(kWG) reduce_slabs(const ReduceParams p)
@@ -830,8 +942,9 @@ __global__ void __launch_bounds__(kWG) reduce_slabs(const ReduceParams p)
     const int i = blockIdx.x * kWG + threadIdx.x;
     if (i >= p.n) return;
     float4 a = p.accumulate ? p.out[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const int nslab = p.run.bi ? run_slab_count(i, p.run) : p.nslab;
 #pragma unroll 8
-    for (int s = 0; s < p.nslab; ++s) {
+    for (int s = 0; s < nslab; ++s) {
         const float4 q = p.slabs[(size_t)s * p.slab_stride + i];
         a.x += q.x; a.y += q.y; a.z += q.z;
     }

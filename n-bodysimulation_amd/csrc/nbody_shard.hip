@@ -140,7 +140,7 @@ int phase_compute(nbody_shard* s)
     // symmetric schedule. The own block against itself is issued in two halves: the first hides the all-gather, the
     // second (phase_finish) hides the exchange. The sums land in `a` in a fixed order: cross launches, own block, received.
     HIP_TRY(hipMemsetAsync(s->a, 0, (size_t)p.shard * sizeof(float4), s->compute));
-    if (int rc = nbody_accel_square_part(c, nb(s->x), nb(s->a), p.i0, p.i1, 1, 0, 2)) return rc;
+    if (int rc = nbody_accel_square_part(c, nb(s->x), nb(s->a), p.i0, p.i1, 1, 0, p.world > 1 ? 2 : 1)) return rc;
     if (s->timing && s->gather_posted) HIP_TRY(hipEventRecord(s->timed.back().local_done, s->compute));
     if (s->gather_posted) HIP_TRY(hipStreamWaitEvent(s->compute, s->ev_gathered, 0));
     if (p.world == 1) return NBODY_OK;
@@ -174,7 +174,7 @@ int phase_finish(nbody_shard* s)
 {
     const nbody_shard_plan_t& p = s->plan;
     if (p.shard == 0) return NBODY_OK;
-    if (p.schedule == NBODY_SCHEDULE_SYMMETRIC) {  // second half of the own block (+ its slab sum), while the exchange runs
+    if (p.schedule == NBODY_SCHEDULE_SYMMETRIC && p.world > 1) {  // second half of the own block (+ its slab sum), while the exchange runs
         if (int rc = nbody_accel_square_part(s->ctx, nb(s->x), nb(s->a), p.i0, p.i1, 1, 1, 2)) return rc;
         if (s->timing && !s->timed.empty() && s->timed.back().exchanged) HIP_TRY(hipEventRecord(s->timed.back().own_done, s->compute));
     }

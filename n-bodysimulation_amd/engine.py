@@ -92,6 +92,10 @@ class Context:
         """Block shape of the symmetric kernel (64*waves*bodies_per_lane bodies per block); 0 = auto."""
         check(self._lib.nbody_ctx_set_symmetric_shape(self._h, waves, bodies_per_lane))
 
+    def set_symmetric_runs(self, mode: int) -> None:
+        """Run-based decomposition of the symmetric kernel: -1 where the cost estimate prefers it, 0 never, 1 always."""
+        check(self._lib.nbody_ctx_set_symmetric_runs(self._h, mode))
+
     def set_stream(self, stream: Optional[torch.cuda.Stream]) -> None:
         self._stream = stream  # keep it alive
         check(self._lib.nbody_ctx_set_stream(self._h, C.c_void_p(stream.cuda_stream) if stream is not None else None))
@@ -112,7 +116,7 @@ class Context:
         """What a whole step of n bodies launches (symmetric or one-sided kernel, slabs, pair evaluations)."""
         sym, blk, slabs, wgs, ev = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_double()
         check(self._lib.nbody_ctx_step_info(self._h, n, C.byref(sym), C.byref(blk), C.byref(slabs), C.byref(wgs), C.byref(ev)))
-        return {"symmetric": bool(sym.value), "block_bodies": blk.value, "slabs": slabs.value,
+        return {"symmetric": bool(sym.value), "runs": sym.value == 2, "block_bodies": blk.value, "slabs": slabs.value,
                 "workgroups": wgs.value, "evaluated_pairs": ev.value}
 
     def step(self, x: torch.Tensor, a: torch.Tensor, v: torch.Tensor, steps: int = 1) -> None:

@@ -155,6 +155,45 @@ def test_symmetric_kernel_shapes_vs_oracle(nb, oracle, waves, bpl, n, init):
     assert np.abs(a.cpu().numpy() - 2 * ag)[:, :3].max() / amax <= 1e-6
 
 
+@pytest.mark.parametrize("bpl", [8, 10])
+@pytest.mark.parametrize("n,init", [(700, 0), (4099, 1), (6400, 0), (20000, 1)])
+def test_symmetric_kernel_in_runs_vs_oracle(nb, oracle, bpl, n, init):
+    """The run-based decomposition (independent waves, units of one 64-body chunk): accelerations against the
+    fp64-accumulated CPU sums at sizes that are and are not multiples of the 64*bpl I-block, momentum balance, w = 0,
+    whole steps equal to force + integrate, run-to-run bitwise reproducibility."""
+    x0 = nb.engine.seeded_bodies(n, init, 11)
+    ctx = nb.engine.Context(kernel=nb.KERNEL_SYMMETRIC, dt=0.01)
+    ctx.set_symmetric_shape(0, bpl)
+    ctx.set_symmetric_runs(1)
+    info = ctx.step_info(n)
+    assert info["symmetric"] and info["runs"] and info["block_bodies"] == 64 * bpl
+    x = torch.from_numpy(x0).cuda()
+    a = torch.full((n, 4), 3.0, device="cuda")
+    ctx.accel_range(x, a, 0, n, 0, n)
+    ctx.sync()
+    ag = a.cpu().numpy()
+    truth = oracle.accel_range(x0, 0, n, eps2=0.002, f64acc=True)
+    amax = np.abs(truth[:, :3]).max()
+    assert np.abs(ag - truth)[:, :3].max() / amax <= 1e-5
+    assert np.all(ag[:, 3] == 0)
+    m = x0[:, 3:4].astype(np.float64)
+    assert np.abs((m * ag[:, :3]).sum(0)).max() / (m * np.abs(ag[:, :3])).sum() < 1e-6
+    a2 = torch.zeros_like(a)
+    ctx.accel_range(x, a2, 0, n, 0, n)
+    ctx.sync()
+    assert torch.equal(a, a2)
+    # a whole step through nbody_step: the integrate sums the same slabs
+    v = torch.zeros_like(x)
+    a3 = torch.zeros_like(x)
+    x1 = x.clone()
+    ctx.step(x1, a3, v, 1)
+    ctx.sync()
+    assert torch.equal(a3, a)
+    xs, vs = x0.copy(), np.zeros_like(x0)
+    oracle.integrate(xs, vs, ag, dt=0.01)
+    assert same_bits(x1.cpu().numpy(), xs) and same_bits(v.cpu().numpy(), vs)
+
+
 def test_symmetric_step_trajectory_and_determinism(nb, oracle):
     """Whole steps through nbody_step with the symmetric kernel forced at a size the oracle finishes:
     K=10 steps vs the Jacobi oracle, bitwise run-to-run reproducibility, integrate bit-exact."""
