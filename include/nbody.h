@@ -104,7 +104,8 @@ int nbody_default_ctx(nbody_ctx** out);
 
 /* ---- contexts ---------------------------------------------------------------------------- */
 
-/* A context owns a device id, a stream and the slab workspace. `device` < 0 = current device. */
+/* A context owns a device id, a stream and the slab workspace. `device` < 0 = current device. A context (and a shard built
+ * on it) is used by one host thread at a time; different contexts are independent (nbody_last_error() is per thread). */
 int nbody_ctx_create(nbody_ctx** out, int device);
 int nbody_ctx_destroy(nbody_ctx* ctx);
 
