@@ -375,6 +375,11 @@ int nbody_plan(int n_targets, int n_sources, int kernel, int tile, int bodies_pe
 int nbody_plan_symmetric(int n, int num_cu, int waves, int bodies_per_lane, int* out_waves, int* out_bodies_per_lane,
                          int* out_blocks, int* out_workgroups);
 
+/* Waves per SIMD the library's cost estimates assume for the fp32 symmetric kernels with this many stationary bodies per
+ * lane (2 at 10, 3 at 8, 5 at 4, 8 at 2): a property of the compiled kernels' register allocation, checked against the
+ * compiler's own resource report by tests/test_build_resources.py. 0 for an unsupported count. */
+int nbody_plan_symmetric_occupancy(int bodies_per_lane);
+
 #ifdef __cplusplus
 }
 #endif

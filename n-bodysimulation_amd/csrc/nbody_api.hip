@@ -215,9 +215,14 @@ constexpr int kSymCands = 9;
 // (41.33 * bpl + 22.6) cycles — 8 bpl/2 packed ops at 4.15, bpl v_rsq_f32 at 8.13, 10 per-step instructions at 2.26
 // (tools/valu_mb.hip). Checked against tools/smalln_probe.py sweeps from 32768 to 1048576 bodies
 // (profiles/r02_shape_probe_{mid,large}.jsonl): it ranks the shapes as measured at every size.
+// Waves per SIMD the register allocation of force_sym<SymPacked<bpl>> / force_sym_run allows. This is a COMPILER OUTPUT
+// (196 / 164 / 92 / 60 VGPRs with ROCm 7.2) that the cost estimates below rely on: tests/test_build_resources.py compiles
+// this file with -Rpass-analysis=kernel-resource-usage and checks every shipped instantiation against this table.
+int sym_waves_per_simd(int bpl) { return bpl >= 10 ? 2 : bpl >= 8 ? 3 : bpl >= 4 ? 5 : 8; }
+
 double sym_cost(int W, int bpl, long tasks, double slab_bytes, int num_cu)
 {
-    const int wps = bpl >= 10 ? 2 : bpl >= 8 ? 3 : bpl >= 4 ? 5 : 8;      // waves per SIMD the VGPR count allows
+    const int wps = sym_waves_per_simd(bpl);                                // waves per SIMD the VGPR count allows
     const long simds = 4L * num_cu;
     const long slots = simds * wps / W;                                     // resident workgroups
     const long full = tasks / slots, rest = tasks - full * slots;
@@ -323,7 +328,7 @@ bool run_resolve(const nbody_ctx* c, int n, RunShape* out, double* cost_out)
         y.nbi = (n + y.layout.bi - 1) / y.layout.bi;
         y.layout.L = 1;
         y.nunits = nbk::run_prefix(y.nbi, y.layout);
-        const int wps = bpl >= 10 ? 2 : 3;
+        const int wps = sym_waves_per_simd(bpl);
         const long simds = 4L * c->num_cu, slots = simds * wps;
         long L = (y.nunits + slots - 1) / slots;   // every worker resident at once
         if (L < 1) L = 1;
@@ -723,6 +728,12 @@ int nbody_plan_symmetric(int n, int num_cu, int waves, int bodies_per_lane, int*
     if (out_blocks) *out_blocks = y.nb;
     if (out_workgroups) *out_workgroups = y.grid;
     return NBODY_OK;
+}
+
+int nbody_plan_symmetric_occupancy(int bodies_per_lane)
+{
+    if (bodies_per_lane < 2 || bodies_per_lane > 16) return 0;
+    return sym_waves_per_simd(bodies_per_lane);
 }
 
 int nbody_ctx_launch_info(nbody_ctx* c, int n_targets, int n_sources, int* jsplit, int* blocks, int* lds_bytes)

@@ -1,0 +1,82 @@
+"""Compiler-dependent assumptions of the launch-shape logic, checked against the compiler's own report.
+
+`sym_cost` / `run_resolve` (n-bodysimulation_amd/csrc/nbody_api.hip) rank the symmetric kernel's block shapes with the number
+of waves per SIMD each instantiation's register allocation allows — a COMPILER OUTPUT, not a property of the source. A ROCm
+update that pushed `SymPacked<10>` past 256 VGPRs, or made any hot kernel spill to scratch, would halve the rate silently.
+`make -C n-bodysimulation_amd/csrc resources` compiles the product's device code with the product's flags plus
+`-Rpass-analysis=kernel-resource-usage`; this file parses that report. No GPU needed (hipcc cross-compiles gfx950).
+"""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPORT = os.path.join(ROOT, "build", "kernel_resources.txt")
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "n-bodysimulation_amd", "csrc"), "resources"], check=True)
+    cur, res = None, {}
+    for ln in open(REPORT, errors="replace"):
+        m = re.search(r"remark:\s+Function Name: (\S+)", ln)
+        if m:
+            cur = m.group(1)
+            res[cur] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\S+) \[-Rpass", ln)
+        if m and cur:
+            res[cur][m.group(1).strip()] = m.group(2)
+    assert res, "no kernel-resource-usage remarks in " + REPORT
+    names = subprocess.run(["c++filt"] + list(res), check=True, capture_output=True, text=True).stdout.splitlines()
+    out = {}
+    for mangled, name in zip(res, names):
+        name = re.sub(r"^void ", "", name)
+        name = re.sub(r"\(.*$", "", name)             # drop the parameter list
+        out[name] = {k: (int(v) if v.lstrip("-").isdigit() else v) for k, v in res[mangled].items()}
+    return out
+
+
+def _get(kernels, name):
+    assert name in kernels, f"{name} is not among the compiled kernels: {sorted(kernels)}"
+    return kernels[name]
+
+
+def test_every_kernel_is_free_of_scratch_and_spills(kernels):
+    assert len(kernels) >= 30
+    for name, r in kernels.items():
+        assert r["ScratchSize"] == 0, (name, r)
+        assert r["VGPRs Spill"] == 0 and r["SGPRs Spill"] == 0, (name, r)
+        assert r["Dynamic Stack"] == "False", (name, r)
+
+
+@pytest.mark.parametrize("bpl,waves_list", [(10, (4, 2, 1)), (8, (4, 2, 1)), (4, (2, 1)), (2, (1,))])
+def test_symmetric_kernel_occupancy_is_what_the_cost_model_assumes(nb, kernels, bpl, waves_list):
+    want = nb.load().nbody_plan_symmetric_occupancy(bpl)
+    assert want == {10: 2, 8: 3, 4: 5, 2: 8}[bpl]
+    for w in waves_list:
+        r = _get(kernels, f"nbk::force_sym<nbk::SymPacked<{bpl}>, {w}, 1>")
+        assert r["Occupancy"] == want, (bpl, w, r)
+        assert r["AGPRs"] == 0 and r["VGPRs"] <= 512 // want, (bpl, w, r)
+        assert r["LDS Size"] == 64 * w * bpl * 16        # one float4 of J-side sums per body of the block
+
+
+def test_run_kernels_occupancy(nb, kernels):
+    for bpl in (10, 8):
+        r = _get(kernels, f"nbk::force_sym_run<nbk::SymPacked<{bpl}> >")
+        assert r["Occupancy"] == nb.load().nbody_plan_symmetric_occupancy(bpl), r
+        assert r["LDS Size"] == 0
+
+
+def test_fp64_kernel_occupancy(kernels):
+    r = _get(kernels, "nbk::force_sym<nbk::SymF64<6>, 4, 1>")       # the default fp64 shape: two waves per SIMD
+    assert r["Occupancy"] == 2 and r["AGPRs"] == 0, r
+    r = _get(kernels, "nbk::force_sym<nbk::SymF64<8>, 4, 1>")       # on request only: one wave per SIMD
+    assert r["Occupancy"] == 1, r
+
+
+def test_one_sided_default_shape(kernels):
+    r = _get(kernels, "nbk::force_lds<nbk::MathPacked<4>, 2048, 8, 1, 0, 256>")
+    assert r["LDS Size"] == 2 * 2048 * 16 and r["Occupancy"] >= 2, r
