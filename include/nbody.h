@@ -60,6 +60,11 @@ enum {
 
 /* Arithmetic flavour of the force kernel. */
 enum {
+    /* The d*d*d overflow corner (validation.cpp:16 == kernel.cu:20): the reference evaluates 1.0f/sqrtf(d*d*d), which  */
+    /* overflows for r > ~2.6e6 and makes such a pair contribute EXACTLY 0. Only NBODY_KERNEL_STRICT reproduces that.    */
+    /* FAST / ONESIDED / SYMMETRIC evaluate rsq(d)^3, which does not overflow there: they keep the physically correct    */
+    /* term m/r^2 the reference drops (<= 1e9/(2.6e6)^2 = 1.5e-4 with the reference's masses, ~1e-7 of a typical max|a|); */
+    /* results stay finite for any finite input (tests/test_gpu_parity.py::test_fast_kernels_at_the_overflow_corner).    */
     NBODY_KERNEL_FAST = 0,      /* packed fp32, v_rsq_f32, fma; tolerance-level parity. A whole step (or a  */
                                 /* square block of nbody_accel_range) of >= 12288 bodies runs the SYMMETRIC */
                                 /* kernel, anything else the ONESIDED one                                   */

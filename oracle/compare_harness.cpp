@@ -1,7 +1,8 @@
 // compare_harness.cpp — compareHostToDevice of the reference (TestProject/validation.cpp:55-103) as
-// a CHECKER program: it drives the PRODUCT through the C-ABI (simulate()) and the CPU restatement
-// (oracle_step_inplace == the reference's CPU_compute) in lock-step, copies the device arrays back
-// and applies the reference's verify_still_bodies rule to positions, velocities and accelerations.
+// a CHECKER program over oracle/validation_checker.hpp (the reference's validation.h:3-5 signatures): it drives the
+// PRODUCT through the C-ABI (simulate()) and the CPU restatement (CPU_compute == oracle_step_inplace == the reference's
+// CPU_compute) in lock-step, copies the device arrays back and applies the reference's verify_still_bodies rule to
+// positions, velocities and accelerations.
 // TEST INFRASTRUCTURE: lives under oracle/, links both libraries; nothing in the product links it.
 //
 //   compare_host_device [--n N] [--steps K (reference: 1000)] [--init libc|ref|plummer] [--seed S] [--jacobi]
@@ -13,44 +14,11 @@
 #include <vector>
 
 #include "nbody.h"
-#include "nbody_oracle.h"
 
 struct float4 { float x, y, z, w; };
-#include "nbody_compat.hpp"
-
-// validation.h:4 — the reference's name for the CPU step (literal in-place order)
-static void CPU_compute(float4* gX, float4* gA, float4* gV, int N, bool jacobi)
-{
-    if (jacobi) oracle_step_jacobi((ofloat4*)gX, (ofloat4*)gA, (ofloat4*)gV, N, DT, EPS2);
-    else oracle_step_inplace((ofloat4*)gX, (ofloat4*)gA, (ofloat4*)gV, N, DT, EPS2);
-}
-
-// validation.cpp:55-103 with N and the step count as parameters; returns the offender counts
-static int compareHostToDevice(float4* d_bodies, float4* d_accel, float4* d_vel, float4* bodies, float4* accelerations,
-                               float4* velocity, int N, int steps, bool jacobi, int bad[3])
-{
-    std::vector<float4> dToH_bodies(N), dToH_velocity(N), dToH_accelerations(N);
-    const size_t size4 = sizeof(float4) * (size_t)N;
-    for (int i = 0; i < steps; i++) {
-        try {
-            simulate(d_bodies, d_accel, d_vel, N);
-        } catch (const std::exception& e) {
-            std::cerr << e.what() << std::endl;
-            return EXIT_FAILURE;
-        }
-        CPU_compute(bodies, accelerations, velocity, N, jacobi);
-    }
-    if (nbody_device_synchronize() != NBODY_OK) return EXIT_FAILURE;
-    nbody_memcpy_d2h(dToH_bodies.data(), d_bodies, size4);
-    nbody_memcpy_d2h(dToH_velocity.data(), d_vel, size4);
-    nbody_memcpy_d2h(dToH_accelerations.data(), d_accel, size4);
-    std::printf("Starting verification...\n");
-    bad[0] = oracle_verify_still_bodies((ofloat4*)dToH_bodies.data(), (ofloat4*)bodies, N);
-    bad[1] = oracle_verify_still_bodies((ofloat4*)dToH_velocity.data(), (ofloat4*)velocity, N);
-    bad[2] = oracle_verify_still_bodies((ofloat4*)dToH_accelerations.data(), (ofloat4*)accelerations, N);
-    std::printf("Verification complete\n\n");
-    return 0;
-}
+struct float3 { float x, y, z; };
+#include "compat/validation.h"       // include/compat: verify_still_bodies / verify_equality4 / verify_equality3
+#include "validation_checker.hpp"    // oracle/: bodyInteractions_CPU, CPU_compute, compareHostToDevice (validation.h:3-5)
 
 int main(int argc, char** argv)
 {
@@ -83,7 +51,7 @@ int main(int argc, char** argv)
     nbody_memcpy_h2d(d_vel, velocity.data(), size4);
     nbody_memcpy_h2d(d_accel, accelerations.data(), size4);
     int bad[3] = {0, 0, 0};
-    const int rc = compareHostToDevice(d_bodies, d_accel, d_vel, bodies.data(), accelerations.data(), velocity.data(), n, steps, jacobi, bad);
+    const int rc = compareHostToDevice_counts(d_bodies, d_accel, d_vel, bodies.data(), accelerations.data(), velocity.data(), n, steps, jacobi, bad);
     std::printf("{\"n\": %d, \"steps\": %d, \"cpu_order\": \"%s\", \"bad_positions\": %d, \"bad_velocities\": %d, \"bad_accelerations\": %d}\n", n,
                 steps, jacobi ? "jacobi" : "inplace", bad[0], bad[1], bad[2]);
     nbody_free_device(d_bodies);

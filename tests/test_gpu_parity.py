@@ -65,6 +65,45 @@ def test_strict_overflow_corner_and_coincident_bodies(nb, oracle):
     assert np.all(a[10, :3] == 0)
 
 
+@pytest.mark.parametrize("kernel,shape", [("fast", None), ("onesided", None), ("symmetric", (1, 2)), ("symmetric", (2, 4))])
+def test_fast_kernels_at_the_overflow_corner(nb, kernel, shape):
+    """What the FAST / ONESIDED / SYMMETRIC kernels do where the reference's `d*d*d` overflows (r > 2.6e6: the reference's
+    term is exactly 0, validation.cpp:16 == kernel.cu:20). They evaluate rsq(d)^3, which does NOT
+    overflow there, so they keep the physically correct (tiny) term m/r^2 the reference drops. Stated, bounded and finite:
+      * every value finite, also for the far body (whose every pair is beyond the overflow radius);
+      * against the fp64 sum WITHOUT the overflow: the usual 1e-5 of max|a|; the far body itself to 1e-4 of its own |a|;
+      * against the strict kernel (the reference's arithmetic): the difference is that one dropped term, at most
+        m_far / r_min^2, plus the usual tolerance.
+    DESIGN.md 2 and include/nbody.h state the same."""
+    n, far = 1500, 10
+    x0 = _rand_bodies(n, 5)
+    x0[far, :3] = [4e6, 0, 0]
+    x0[far, 3] = 1e9
+    k = {"fast": nb.KERNEL_FAST, "onesided": nb.KERNEL_ONESIDED, "symmetric": nb.KERNEL_SYMMETRIC}[kernel]
+    sim = nb.engine.Simulation(x0, dt=0.1, eps2=0.002, kernel=k)
+    if shape:
+        sim.ctx.set_symmetric_shape(*shape)
+        assert sim.ctx.step_info(n)["symmetric"]
+    sim.run(1)
+    x, v, a = sim.state()
+    xs, vs, a_strict = _gpu_run(nb, x0, 1, 0.1, 0.002, nb.KERNEL_STRICT)
+    assert np.all(np.isfinite(a)) and np.all(np.isfinite(x)) and np.all(np.isfinite(v))
+    assert np.all(a_strict[far, :3] == 0)                                   # the reference: every pair of the far body overflows
+    p = x0[:, :3].astype(np.float64)
+    r = p[None, :, :] - p[:, None, :]
+    d = (r * r).sum(-1) + np.float64(np.float32(0.002))
+    w = x0[None, :, 3].astype(np.float64) * d ** -1.5
+    w[np.arange(n), np.arange(n)] = 0.0
+    truth = (r * w[:, :, None]).sum(1)
+    amax = np.abs(truth).max()
+    others = np.arange(n) != far
+    assert np.abs(a[others, :3] - truth[others]).max() <= 1e-5 * amax
+    assert np.abs(a[far, :3] - truth[far]).max() <= 1e-4 * np.abs(truth[far]).max()
+    assert np.abs(truth[far]).max() > 0
+    dropped = 1e9 / ((4e6 - 1e5) ** 2)                                       # the largest term the reference drops
+    assert np.abs(a[others, :3] - a_strict[others, :3]).max() <= 1.01 * dropped + 1e-5 * amax
+
+
 # ---- T2: fast kernel, single step --------------------------------------------------------------
 
 @pytest.mark.parametrize("n,init,dt,scale", [(1024, 0, 0.1, 1e5), (1000, 0, 0.1, 1e5), (1024, 1, 0.01, 1.0),
