@@ -11,15 +11,26 @@ the half-kick/drift integrate (TestProject/kernel.cu:80-130 in the reference).
 Workload (BASELINE.json):
   --gpus 1   N = 262144 bodies, fp32 (configs[2], the size the metric is quoted on).
   --gpus G>1 N = 1048576 bodies (configs[3]) block-partitioned over the G ranks, positions all-gathered
-             once per step (RCCL); STRONG scaling: the same system at every G. `--scaling weak` instead
-             runs N(G) = 262144*sqrt(G) rounded to 8192*G bodies (equal pairs per GPU).
+             once per step (RCCL); STRONG scaling: the same system at every G >= 2. The 1-GPU point of THAT series is
+             `--gpus 1 --bodies 1048576` (the default 1-GPU run is configs[2]; an offline figure for it is reported
+             as `single_gpu_same_n`). `--scaling weak` instead runs N(G) = 262144*sqrt(G) rounded to 8192*G bodies
+             (equal pairs per GPU, the default 1-GPU run being its first point).
   --bodies overrides N; --dtype f64 is configs[4] (single GPU).
 
-Timing: W warm-up steps, then R repeats (R >= 3, enough for >= 3 s in all; --repeats overrides) of
-EXACTLY K steps each, every repeat bracketed by a barrier + device synchronise on both sides and
-reduced with MAX over ranks. `ms_per_step` and `value` come from the MEDIAN repeat; min/max are
-reported beside it. `value` = N^2 * K / (median repeat time): interactions applied per second, inputs
-resident in HBM before the first repeat starts.
+Multi-GPU runs certify themselves BEFORE the timed loop (this process is the only one that ever sees 8 GPUs):
+  census   every rank's device (PCI bus id, uuid, name) gathered and required to be distinct: `config.rccl`;
+  parity   one untimed sharded step, then every rank compares its own-block accelerations on 4096 sampled bodies with the
+           SINGLE-GPU one-sided kernel over all N sources (product kernel vs product kernel, no CPU checker involved);
+  cross    after the warm-up steps one more all-gather, then per-block checksums of every rank's position array must be
+           identical on all ranks (bit-identical copies): `config.multi_gpu_check`. A failed check exits non-zero.
+`--comm torch` runs the two collectives through torch.distributed (backend nccl = RCCL); `--comm native` through the
+library's own RCCL communicator (nbody_comm_rccl_*, no Python in the step), its id broadcast over the process group.
+
+Timing: the CPU baseline first (rank 0, single GPU runs), then W warm-up steps, then R repeats (enough for >= 10 s of timed
+GPU work, 3 <= R <= 64; --repeats overrides) of EXACTLY K steps each, every repeat bracketed by a barrier + device
+synchronise on both sides and reduced with MAX over ranks. `ms_per_step` and `value` come from the MEDIAN repeat; min/max
+are reported beside it. `value` = N^2 * K / (median repeat time): interactions applied per second, inputs resident in HBM
+before the first repeat starts.
 
 `roofline` is the force kernel's algorithmic FLOP rate — 20 FLOP per interaction times
 the N^2 interactions one launch applies — over its own HIP-event time on its launch stream, against the
@@ -59,14 +70,38 @@ def weak_n(gpus: int) -> int:
 
 def default_workload(world: int, bodies: int, scaling: str):
     """(N, scaling label) for a run on `world` GPUs: BASELINE.json configs[2] on one GPU, configs[3] strong-scaled on
-    several, unless --bodies / --scaling weak say otherwise."""
+    several, unless --bodies / --scaling weak say otherwise. The label follows --scaling at every G (a 1-GPU run is a
+    point of whichever series it is compared with): "strong" = the same N at every G (N = 1048576 for G >= 2; its 1-GPU
+    point is `--gpus 1 --bodies 1048576`), "weak" = N(G) = 262144*sqrt(G), per-GPU pair count fixed."""
     if bodies:
-        return bodies, ("strong" if world > 1 else "weak")
-    if world == 1:
-        return N_SINGLE, "weak"
+        return bodies, "strong"
     if scaling == "weak":
         return weak_n(world), "weak"
+    if world == 1:
+        return N_SINGLE, "strong"
     return N_MULTI, "strong"
+
+
+def device_census(dev):
+    """What this rank runs on, for the cross-rank census (config.rccl.devices)."""
+    import torch
+    p = torch.cuda.get_device_properties(dev)
+    rec = {"rank": int(os.environ.get("RANK", "0")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "index": dev.index,
+           "name": p.name, "cus": p.multi_processor_count, "hbm_gib": round(p.total_memory / 2 ** 30, 1)}
+    for k in ("uuid", "pci_domain_id", "pci_bus_id", "pci_device_id", "gcnArchName"):
+        if hasattr(p, k):
+            v = getattr(p, k)
+            rec[k] = v if isinstance(v, (int, str)) else str(v)
+    rec["visible"] = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or ""
+    rec["pid"] = os.getpid()
+    return rec
+
+
+def device_key(rec):
+    """Identity of the physical device behind a census record."""
+    if "uuid" in rec and rec["uuid"] not in ("", "None"):
+        return ("uuid", rec["uuid"])
+    return ("pci", rec.get("pci_domain_id"), rec.get("pci_bus_id"), rec.get("pci_device_id"), rec.get("visible"), rec["index"])
 
 
 def ensure_built() -> None:
@@ -155,12 +190,14 @@ def cpu_baseline_f64(seconds_budget: float = 10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--repeats", type=int, default=0, help="timed repeats of --steps steps (0 = auto: >= 3 and >= 3 s in all)")
+    ap.add_argument("--repeats", type=int, default=0, help="timed repeats of --steps steps (0 = auto: >= 3 and >= --min-seconds in all)")
+    ap.add_argument("--min-seconds", type=float, default=10.0, help="auto repeats: timed GPU work to accumulate (sustained clocks, "
+                    "and long enough for an external utilisation sampler to see)")
     ap.add_argument("--bodies", dest="n", type=int, default=0, help="number of bodies (default: 262144 on 1 GPU, 1048576 on several)")
-    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="--gpus > 1 without --bodies: strong = N 1048576 "
-                    "at every G (default, BASELINE configs[3]); weak = 262144*sqrt(G) bodies")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="without --bodies: strong = N 1048576 at every "
+                    "G >= 2 (default, BASELINE configs[3]; G = 1 runs configs[2], N = 262144); weak = 262144*sqrt(G) bodies")
     ap.add_argument("--dt", type=float, default=0.01)
     ap.add_argument("--eps2", type=float, default=0.002)
     ap.add_argument("--init", type=int, default=1, help="0 reference cube, 1 Plummer")
@@ -173,9 +210,25 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="f64 = the build's own double-precision variant "
                     "(BASELINE configs[4]; single GPU only)")
-    ap.add_argument("--backend", default="nccl", help="collective backend for --gpus > 1: nccl (RCCL; default) or gloo "
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1: nccl (RCCL; default) or gloo "
                     "(rehearsal of the multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--comm", default="torch", choices=["torch", "native"], help="who runs the step's two collectives: torch = "
+                    "torch.distributed on the --backend group; native = the library's own RCCL communicator (nbody_comm_rccl_*), "
+                    "its unique id broadcast through the --backend group, which then only carries barriers and reductions")
+    ap.add_argument("--fake-hosts", action="store_true", help="rehearsal only: give every rank its own NCCL_HOSTID so that RCCL "
+                    "accepts several ranks on ONE GPU (it then talks over its socket transport on the loopback interface)")
+    ap.add_argument("--force-sharded", action="store_true", help="take the multi-GPU code path (process group, census, sharded step, "
+                    "checks) even with ONE rank — what a 1-GPU box can exercise of it over real RCCL")
+    ap.add_argument("--no-multi-gpu-check", action="store_true", help="skip the in-run parity / cross-rank checks (world > 1)")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.fake_hosts:   # before RCCL is loaded
+        os.environ["NCCL_HOSTID"] = f"nbody-bench-host-{rank}"
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
 
     ensure_built()   # before the process group and before any GPU call; ranks serialise on a file lock
 
@@ -184,9 +237,6 @@ def main():
     import torch.distributed as dist
     import nbody_amd
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("for --gpus > 1 launch through torch.distributed.run (one rank per GPU)")
@@ -194,12 +244,31 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     ndev = torch.cuda.device_count()
-    if args.backend == "nccl" and world > ndev:
-        raise SystemExit(f"{world} ranks but {ndev} GPU(s): RCCL needs one GPU per rank (use --backend gloo to rehearse)")
+    shared_gpu = args.fake_hosts or (args.backend != "nccl" and args.comm != "native")
+    if world > ndev and not shared_gpu:
+        raise SystemExit(f"{world} ranks but {ndev} GPU(s): RCCL needs one GPU per rank (use --backend gloo, or --fake-hosts, to rehearse)")
     dev = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(dev)
-    if world > 1:
+    f64 = args.dtype == "f64"
+    multi = world > 1 or args.force_sharded          # the sharded code path
+    if f64 and multi:
+        raise SystemExit("--dtype f64 is a single-GPU variant")
+
+    # The CPU baseline goes FIRST (rank 0, single-GPU runs): the GPU phase then runs uninterrupted to the end of the process
+    cpu = None
+    if rank == 0 and not multi and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline_f64() if f64 else cpu_baseline()
+        except Exception as e:  # the baseline must never take the GPU number down with it
+            cpu = {"value": None, "unit": "pairs/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+
+    if multi:
         import datetime
+        if world == 1:   # a single rank not started by torch.distributed.run: rendezvous with itself
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         limit = datetime.timedelta(minutes=5)   # a collective that never completes becomes an error, not a hang
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev, timeout=limit)
@@ -210,10 +279,31 @@ def main():
     x0 = nbody_amd.engine.seeded_bodies(n, args.init, 12345)
     kernel = {"fast": nbody_amd.KERNEL_FAST, "onesided": nbody_amd.KERNEL_ONESIDED, "symmetric": nbody_amd.KERNEL_SYMMETRIC}[args.kernel]
     kopts = dict(kernel=kernel, tile=args.tile, bodies_per_lane=args.bpl, jsplit=args.jsplit)
+    red_dev = dev if args.backend == "nccl" else "cpu"
 
-    f64 = args.dtype == "f64"
-    if f64 and world > 1:
-        raise SystemExit("--dtype f64 is a single-GPU variant")
+    def max_over_ranks(v: float) -> float:
+        if not multi:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- census: did the collective library see `world` ranks on `world` different devices? ------------------------------
+    rccl = None
+    if multi:
+        mine = device_census(dev)
+        recs = [None] * world
+        dist.all_gather_object(recs, mine)
+        recs = sorted(recs, key=lambda r: r["rank"])
+        distinct = len({device_key(r) for r in recs}) == world
+        rccl = {"world": dist.get_world_size(), "backend": dist.get_backend(), "comm": args.comm, "devices": recs,
+                "distinct_devices": distinct, "ranks_seen": sorted(r["rank"] for r in recs) == list(range(world)),
+                "fake_hosts": bool(args.fake_hosts)}
+        if not rccl["ranks_seen"] or rccl["world"] != world:
+            raise SystemExit(f"census: expected ranks 0..{world - 1}, the group reports {rccl['world']} ranks: {recs}")
+        if not distinct and not shared_gpu:
+            raise SystemExit(f"census: {world} ranks but the devices are not distinct: {recs}")
+
     if f64:
         class _F64Sim:   # same alloc/init/H2D sequence as engine.Simulation, double state
             def __init__(self):
@@ -233,19 +323,8 @@ def main():
         ctx = sim.ctx
         run = lambda k: sim.run(k)
         sync = ctx.sync
-        sym64 = kernel != nbody_amd.KERNEL_ONESIDED and (n >= 12288 or kernel == nbody_amd.KERNEL_SYMMETRIC)
-        info = {"symmetric": sym64, "slabs": args.jsplit or "auto", "evaluated_pairs": float(n) * n}
-        if sym64:   # the double-precision rotation kernel: blocks of 64*waves*bpl bodies, each unordered pair once
-            cands = [(4, 6), (2, 4), (1, 2)]
-            if (args.sym_waves, args.sym_bpl) == (4, 8):
-                cands = [(4, 8)]
-            pick = next(((w, b) for (w, b) in cands if (not args.sym_waves or w == args.sym_waves) and (not args.sym_bpl or b == args.sym_bpl)
-                         and n >= 128 * 64 * w * b), cands[-1])
-            blk = 64 * pick[0] * pick[1]
-            nblk = -(-n // blk)
-            info.update({"block_bodies": blk, "slabs": nblk, "workgroups": nblk * (nblk + 1) // 2,
-                         "evaluated_pairs": float(nblk * (nblk + 1) // 2) * blk * blk})
-    elif world == 1:
+        info = ctx.step_info_f64(n)   # the library's own account of what nbody_step_f64 launches
+    elif not multi:
         sim = nbody_amd.engine.Simulation(x0, dt=args.dt, eps2=args.eps2, device=dev.index, **kopts)
         ctx = sim.ctx
         if args.sym_waves or args.sym_bpl:
@@ -256,38 +335,84 @@ def main():
         info = ctx.step_info(n)
     else:
         sim = nbody_amd.sharded.ShardedSimulation(x0, dt=args.dt, eps2=args.eps2, device=dev, sym_waves=args.sym_waves,
-                                                  sym_bpl=args.sym_bpl, **kopts)
+                                                  sym_bpl=args.sym_bpl, comm=args.comm, **kopts)
         ctx = sim.ctx
         run = sim.step
         sync = sim.sync
-        info = ctx.step_info(sim.shard)   # the own-block pass
         plan = sim.plan
-        if plan.schedule == nbody_amd.sharded.SCHEDULE_SYMMETRIC:   # + the cross launches: each pair once, both sides
+        symmetric_schedule = plan.schedule == nbody_amd.sharded.SCHEDULE_SYMMETRIC
+        info = ctx.square_info(sim.shard, 2 if symmetric_schedule and world > 1 else 1)   # the own-block pass as it is launched (two parts)
+        if symmetric_schedule:   # + the cross launches: each pair once, both sides
             cross = sum(float(plan.launch[l].i1 - plan.launch[l].i0) * plan.launch[l].count for l in range(plan.n_launches))
-        else:                                                       # + own targets x every other block, one-sided
+        else:                    # + own targets x every other block, one-sided
             cross = float(sim.shard) * (sim.n_pad - sim.shard)
         info["evaluated_pairs"] += cross
         info["schedule"] = {0: "canonical", 1: "onesided", 2: "symmetric"}[plan.schedule]
         info["cross_launches"] = [[plan.launch[l].i0, plan.launch[l].i1, plan.launch[l].j0, plan.launch[l].count] for l in range(plan.n_launches)]
 
-    red_dev = dev if args.backend == "nccl" else "cpu"
-
     def barrier():
         sync()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if multi:
             dist.barrier()
 
-    def max_over_ranks(v: float) -> float:
-        if world == 1:
-            return v
-        t = torch.tensor([v], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+    # ---- multi-GPU self-check, part 1: one sharded step against the single-GPU kernel -------------------------------------
+    check = None
+    steps_before_timing = args.warmup
+    if multi and not args.no_multi_gpu_check:
+        run(1)                       # accelerations at the initial positions, through the whole sharded machinery
+        barrier()
+        steps_before_timing = max(args.warmup - 1, 0)
+        ref_ctx = nbody_amd.engine.Context(device=dev.index, dt=args.dt, eps2=args.eps2, kernel=nbody_amd.KERNEL_ONESIDED)
+        xfull = torch.zeros((sim.n_pad, 4), dtype=torch.float32, device=dev)
+        xfull[:n] = torch.from_numpy(x0).to(dev)
+        if sim.n_pad > n:            # the shard's padding bodies: massless, on top of body 0
+            xfull[n:] = xfull[0]
+            xfull[n:, 3] = 0.0
+        samples = min(4096, sim.shard)
+        pieces = 4 if samples >= 1024 else 1
+        per = samples // pieces
+        worst, amax = 0.0, 0.0
+        for k in range(pieces):      # sample ranges spread over the own block
+            off = (sim.shard - per) * k // max(pieces - 1, 1)
+            i0 = sim.i0 + off
+            ref = torch.empty((per, 4), dtype=torch.float32, device=dev)
+            ref_ctx.accel_range(xfull, ref, i0, i0 + per, 0, sim.n_pad)
+            ref_ctx.sync()
+            got = sim.a[off:off + per]
+            worst = max(worst, float((got - ref)[:, :3].abs().max().item()))
+            amax = max(amax, float(ref[:, :3].abs().max().item()))
+        ref_ctx.close()
+        del xfull
+        rel = worst / amax if amax > 0 else float("inf")
+        rel_all = max_over_ranks(rel)
+        finite = max_over_ranks(0.0 if bool(torch.isfinite(sim.a).all().item()) else 1.0) == 0.0
+        check = {"sampled_bodies_per_rank": per * pieces, "reference": "single-GPU one-sided kernel (nbody_accel_range) over all sources, on every rank's own GPU",
+                 "max_rel_da": rel_all, "tolerance": 5e-5, "finite": finite}
+        if not (rel_all <= 5e-5 and finite):
+            if rank == 0:
+                print(json.dumps({"error": "multi_gpu_check failed", "multi_gpu_check": check, "rccl": rccl}), flush=True)
+            raise SystemExit(3)
 
-    run(args.warmup)
+    run(steps_before_timing)
     barrier()
-    if world > 1:
+
+    # ---- part 2: after the warm-up steps every rank's copy of every block must be bit-identical ----------------------------
+    if check is not None:
+        sim.refresh_positions()
+        sums = sim.block_checksums().cpu()
+        alls = [None] * world
+        dist.all_gather_object(alls, sums.tolist())
+        equal = all(a == alls[0] for a in alls)
+        check["x_bitwise_equal_across_ranks"] = equal
+        check["steps_checked"] = 1 + steps_before_timing
+        if not equal:
+            if rank == 0:
+                print(json.dumps({"error": "positions differ between ranks", "multi_gpu_check": check, "rccl": rccl}), flush=True)
+            raise SystemExit(3)
+        barrier()
+
+    if multi:
         sim.comm_timing(True)
     ctx.timing(True)
     repeats, kernel_ms, kernel_launches = [], [], 0
@@ -302,16 +427,16 @@ def main():
         repeats.append(elapsed)
         kernel_ms.append(ms)
         kernel_launches += launches
-        if args.repeats <= 0 and len(repeats) == 1:
-            target = min(max(3, int(math.ceil(3.0 / max(elapsed, 1e-6)))), 25)   # same on every rank: from the reduced time
+        if args.repeats <= 0 and len(repeats) == 1:   # same on every rank: from the reduced time
+            target = min(max(3, int(math.ceil(args.min_seconds / max(elapsed, 1e-6)))), 64)
     ctx.timing(False)
-    comm = sim.comm_report() if world > 1 else None
+    comm = sim.comm_report() if multi else None
 
     elapsed = statistics.median(repeats)
     pairs_step = float(n) * n
     value = pairs_step * args.steps / elapsed
     # roofline of the dominant kernel (force accumulation), from its own event time on this rank
-    rank_pairs = float(sim.shard) * sim.n_pad if world > 1 else pairs_step            # interactions this rank applies per step
+    rank_pairs = float(sim.shard) * sim.n_pad if multi else pairs_step            # interactions this rank applies per step
     launches_per_step = max(kernel_launches // (len(repeats) * args.steps), 1)
     kernel_s_step = sum(kernel_ms) * 1e-3 / (len(repeats) * args.steps)                 # force-kernel time per step
     achieved = FLOP_PER_PAIR * rank_pairs / kernel_s_step / 1e12 if kernel_s_step > 0 else 0.0
@@ -319,16 +444,27 @@ def main():
     achieved_eval = FLOP_PER_PAIR * evaluated / kernel_s_step / 1e12 if kernel_s_step > 0 else 0.0
     peak = FP64_VECTOR_PEAK_TFLOPS if f64 else FP32_VECTOR_PEAK_TFLOPS
     symmetric = bool(info.get("symmetric"))
-    traffic = traffic_note = None
+    traffic = traffic_note = traffic_source = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if world == 1 and not f64 and os.path.exists(tpath):
+    if not multi and not f64 and os.path.exists(tpath):
         try:   # PMC passes are taken offline (tools/pmc.sh); valid only for the launch shape they were taken at
             t = json.load(open(tpath))
             if t.get("n_bodies") == n and t.get("symmetric") == symmetric and t.get("slabs") == info.get("slabs"):
                 traffic = t.get("force_kernel_hbm_bytes_per_launch")
                 traffic_note = t.get("note")
+                traffic_source = "OFFLINE PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc.sh), kept in profiles/traffic.json for this launch shape; NOT measured in this run"
         except Exception:
             traffic = None
+
+    same_n = None
+    spath = os.path.join(ROOT, "profiles", "single_gpu_reference.json")
+    if multi and os.path.exists(spath):
+        try:
+            ref = json.load(open(spath)).get(str(n))
+            if ref:
+                same_n = dict(ref, measured_in_this_run=False)
+        except Exception:
+            same_n = None
 
     fp_diff = None
     if f64:
@@ -356,20 +492,29 @@ def main():
         "dtype": args.dtype,
         "data": "synthetic",
         "repeats": len(repeats),
+        "timed_seconds": sum(repeats),
         "ms_per_step_min": min(repeats) / args.steps * 1e3,
         "ms_per_step_max": max(repeats) / args.steps * 1e3,
+        "per_gpu_value": value / world,
+        **({"single_gpu_same_n": same_n} if same_n else {}),
         "config": {
             "workload": f"all-pairs gravity step, N={n} bodies, {'fp64' if f64 else 'fp32'}, {'Plummer' if args.init == 1 else 'reference-cube'} init seed 12345, "
                         f"dt={args.dt}, eps2={args.eps2}" + (f", {world} GPUs, {scaling} scaling" if world > 1 else ""),
             "n_bodies": n,
             "pairs_per_step": pairs_step,
-            "partition": "single GPU" if world == 1 else (f"{world} contiguous blocks of {sim.shard} bodies, {args.backend} all-gather of positions per step" +
+            "scaling_series": ("strong: N = 1048576 at every G >= 2 (BASELINE configs[3]); the default 1-GPU run is configs[2] (N = 262144), "
+                               "the same-N 1-GPU point is `--gpus 1 --bodies 1048576`" if scaling == "strong" and not args.n else
+                               "weak: N(G) = 262144*sqrt(G) rounded to 8192*G, equal pairs per GPU" if scaling == "weak" else f"--bodies {n} at every G"),
+            "partition": "single GPU" if not multi else (f"{world} contiguous blocks of {sim.shard} bodies, all-gather of positions per step over {args.comm} "
+                                                                  f"({'library RCCL communicator' if args.comm == 'native' else 'torch.distributed ' + args.backend})" +
                                                                   (", every unordered pair once across the ranks, J-side sums exchanged (grouped send/recv)" if info.get("schedule") == "symmetric" else "")),
             "kernel": nbody_amd.load().nbody_version().decode(),
             "launch": info,
             "gflops_at_20_flop_per_pair": value * FLOP_PER_PAIR / 1e9,
             **({"fp32_vs_fp64": fp_diff} if fp_diff else {}),
             **({"comm_rank0": comm} if comm else {}),
+            **({"rccl": rccl} if rccl else {}),
+            **({"multi_gpu_check": check} if check else {}),
         },
         "roofline": {
             "bound": "valu",
@@ -378,6 +523,7 @@ def main():
             "unit": "TFLOP/s",
             "frac": achieved / peak,
             "traffic": traffic,
+            **({"traffic_source": traffic_source} if traffic_source else {}),
             **({"traffic_note": traffic_note} if traffic_note else {}),
             "kernel": ("nbk::force_sym<SymF64> (fp64, each unordered pair once)" if symmetric else "nbk::force_f64 (one-sided)") if f64 else ("nbk::force_sym (fp32 packed, each unordered pair once)" if symmetric else "nbk::force_lds (fp32 packed, one-sided)"),
             "kernel_ms_per_step": kernel_s_step * 1e3,
@@ -390,19 +536,18 @@ def main():
             "frac_evaluated": achieved_eval / peak,
             "note": ("fp64 vector-ALU bound; peak = 78.6 TFLOP/s fp64 vector" if f64 else
                      "fp32 vector-ALU bound (no MFMA, HBM traffic is O(N) per step); peak = 157.3 TFLOP/s fp32 vector = fp32 MFMA peak. "
-                     "achieved/frac: 20 FLOP x interactions applied (N^2, the metric's convention); achieved_evaluated/frac_evaluated: "
-                     "20 FLOP x pair evaluations actually executed (the symmetric kernel evaluates each unordered pair once and applies it to both bodies)"),
+                     "achieved/frac: 20 FLOP x interactions applied (N^2, the metric's convention: SURVEY.md 8d's per-unit figure x the units one launch processes); "
+                     "achieved_evaluated/frac_evaluated: 20 FLOP x pair evaluations actually EXECUTED (the symmetric kernel evaluates each unordered pair once and "
+                     "applies it to both bodies) — the figure to read as ALU work done per second"),
         },
     }
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                line["cpu_baseline"] = cpu_baseline_f64() if f64 else cpu_baseline()
-            except Exception as e:  # the baseline must never take the GPU number down with it
-                line["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
+        sim.close()
         dist.destroy_process_group()
 
 

@@ -368,6 +368,17 @@ int nbody_ctx_launch_info(nbody_ctx* ctx, int n_targets, int n_sources, int* jsp
 int nbody_ctx_step_info(nbody_ctx* ctx, int n, int* symmetric, int* block_bodies, int* slabs, int* workgroups,
                         double* evaluated_pairs);
 
+/* The same for the fp64 step (nbody_step_f64): symmetric = 1 for the double-precision rotation kernel, 0 for the one-sided one. */
+int nbody_ctx_step_info_f64(nbody_ctx* ctx, int n, int* symmetric, int* block_bodies, int* slabs, int* workgroups,
+                            double* evaluated_pairs);
+
+/* What nbody_accel_square_part(.., nparts) launches for a block of n bodies against itself: with one part this is
+ * nbody_ctx_step_info; with several parts only the block-pair task list splits, so the block-pair kernel runs wherever the
+ * symmetric kernel applies (also at sizes where a whole step would use the run-based variant). What one rank's own-block
+ * pass of the sharded step launches (nparts = 2 when world > 1). */
+int nbody_ctx_square_info(nbody_ctx* ctx, int n, int nparts, int* symmetric, int* block_bodies, int* slabs, int* workgroups,
+                          double* evaluated_pairs);
+
 /* The same resolution without a context or a device (pure host logic, for tests and tooling):
  * given the user's kernel/tile/bodies_per_lane/jsplit choices (0 = auto) and a CU count, what the
  * launcher would pick. blocks_x = workgroups along the targets; the grid is blocks_x * jsplit. */

@@ -376,6 +376,30 @@ bool sym_wanted(const nbody_ctx* c, int n, SymShape* out)
     return false;
 }
 
+// The fp64 step's symmetric shape: the rotation kernel in double (FAST from kSymMinAuto bodies, or SYMMETRIC). Shapes (waves,
+// bodies per lane): (4,6) measured best at N=262144 (26.4 ms/step; (4,8) 27.1 with 256 VGPR + 23 AGPR and one wave per
+// SIMD, (4,4) 27.2, (2,6) 26.8); (4,8) stays selectable through nbody_ctx_set_symmetric_shape. false = one-sided kernel.
+bool f64_sym_shape(const nbody_ctx* c, int n, int* W, int* BPL, int* nb_out)
+{
+    static const int cand[][2] = {{4, 6}, {2, 4}, {1, 2}, {4, 8}};
+    if (!(c->kernel == NBODY_KERNEL_SYMMETRIC || (c->kernel == NBODY_KERNEL_FAST && n >= kSymMinAuto))) return false;
+    int pick = -1;
+    for (int k = 0; k < 4; ++k) {
+        if (k == 3 && !(c->sym_waves == 4 && c->sym_bpl == 8)) continue;  // only on request
+        if ((c->sym_waves && cand[k][0] != c->sym_waves) || (c->sym_bpl && cand[k][1] != c->sym_bpl)) continue;
+        pick = k;
+        if ((long)n >= 128L * 64 * cand[k][0] * cand[k][1]) break;
+    }
+    if (pick < 0) return false;
+    const int B = 64 * cand[pick][0] * cand[pick][1];
+    const int nb = (n + B - 1) / B;
+    if (nb < 2 || nb > kSymMaxSlabs) return false;
+    *W = cand[pick][0];
+    *BPL = cand[pick][1];
+    *nb_out = nb;
+    return true;
+}
+
 int ensure_xslabs(nbody_ctx* c, size_t bytes)
 {
     if (bytes <= c->xslab_bytes) return NBODY_OK;
@@ -791,6 +815,53 @@ int nbody_ctx_step_info(nbody_ctx* c, int n, int* symmetric, int* block_bodies, 
     if (slabs) *slabs = s.jsplit;
     if (workgroups) *workgroups = s.blocks_x * s.jsplit;
     if (evaluated_pairs) *evaluated_pairs = (double)n * (double)n;
+    return NBODY_OK;
+}
+
+int nbody_ctx_step_info_f64(nbody_ctx* c, int n, int* symmetric, int* block_bodies, int* slabs, int* workgroups, double* evaluated_pairs)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (n < 0) return fail(NBODY_ERR_INVALID, "negative size");
+    int W = 0, BPL = 0, nb = 0;
+    if (f64_sym_shape(c, n, &W, &BPL, &nb)) {
+        const double B = 64.0 * W * BPL;
+        if (symmetric) *symmetric = 1;
+        if (block_bodies) *block_bodies = (int)B;
+        if (slabs) *slabs = nb;
+        if (workgroups) *workgroups = nb * (nb - 1) / 2 + nb;
+        if (evaluated_pairs) *evaluated_pairs = ((double)nb * (nb - 1) / 2 + nb) * B * B;
+        return NBODY_OK;
+    }
+    const int blocks_x = (n + nbk::kWG * 2 - 1) / (nbk::kWG * 2);
+    int js = c->jsplit;
+    if (!js) {
+        js = 1;
+        while (blocks_x * js < 8 * c->num_cu && js < kMaxSplit) js *= 2;
+        const int ntile = (n + 511) / 512;
+        while (js > 1 && ntile / js < 2) js /= 2;
+    }
+    if (symmetric) *symmetric = 0;
+    if (block_bodies) *block_bodies = nbk::kWG * 2;
+    if (slabs) *slabs = js;
+    if (workgroups) *workgroups = blocks_x * js;
+    if (evaluated_pairs) *evaluated_pairs = (double)n * (double)n;
+    return NBODY_OK;
+}
+
+int nbody_ctx_square_info(nbody_ctx* c, int n, int nparts, int* symmetric, int* block_bodies, int* slabs, int* workgroups,
+                          double* evaluated_pairs)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (n < 0 || nparts < 1) return fail(NBODY_ERR_INVALID, "bad square info arguments");
+    // one part: the whole-step logic (runs where the cost estimate prefers them); several parts: only a block-pair task
+    // list splits, so nbody_accel_square_part launches the block-pair kernel wherever the symmetric kernel applies
+    SymShape y{};
+    if (nparts == 1 || !sym_wanted(c, n, &y)) return nbody_ctx_step_info(c, n, symmetric, block_bodies, slabs, workgroups, evaluated_pairs);
+    if (symmetric) *symmetric = 1;
+    if (block_bodies) *block_bodies = y.block;
+    if (slabs) *slabs = y.nb;
+    if (workgroups) *workgroups = y.grid;
+    if (evaluated_pairs) *evaluated_pairs = ((double)y.nb * (y.nb - 1) / 2 + y.nb) * (double)y.block * (double)y.block;
     return NBODY_OK;
 }
 
@@ -1256,22 +1327,12 @@ int nbody_step_f64(nbody_ctx* c, nbody_double4* d_bodies, nbody_double4* d_accel
     q.a = reinterpret_cast<double4*>(d_accelerations);
     q.n = n;
     q.dt = dt;
-    // the symmetric rotation kernel in double (FAST from 16384 bodies, or SYMMETRIC): shapes (waves, bodies per lane)
-    // (4,6) measured best at N=262144 (26.4 ms/step; (4,8) 27.1 with 256 VGPR + 23 AGPR and one wave per SIMD, (4,4) 27.2,
-    // (2,6) 26.8); (4,8) stays selectable through nbody_ctx_set_symmetric_shape
-    static const int cand[][2] = {{4, 6}, {2, 4}, {1, 2}, {4, 8}};
-    if (c->kernel == NBODY_KERNEL_SYMMETRIC || (c->kernel == NBODY_KERNEL_FAST && n >= kSymMinAuto)) {
-        int pick = -1;
-        for (int k = 0; k < 4; ++k) {
-            if (k == 3 && !(c->sym_waves == 4 && c->sym_bpl == 8)) continue;  // only on request
-            if ((c->sym_waves && cand[k][0] != c->sym_waves) || (c->sym_bpl && cand[k][1] != c->sym_bpl)) continue;
-            pick = k;
-            if ((long)n >= 128L * 64 * cand[k][0] * cand[k][1]) break;
-        }
-        if (pick >= 0) {
-            const int W = cand[pick][0], BPL = cand[pick][1], B = 64 * W * BPL;
-            const int nb = (n + B - 1) / B;
-            if (nb >= 2 && nb <= kSymMaxSlabs) {
+    {
+        int W = 0, BPL = 0, nb = 0;
+        if (f64_sym_shape(c, n, &W, &BPL, &nb)) {
+            const int B = 64 * W * BPL;
+            (void)B;
+            {
                 if (int rc = ensure_slabs(c, (size_t)nb * n * sizeof(double4))) return rc;
                 nbk::SymParamsF64 sp{};
                 sp.x = reinterpret_cast<const double4*>(d_bodies);

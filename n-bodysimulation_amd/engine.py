@@ -119,6 +119,21 @@ class Context:
         return {"symmetric": bool(sym.value), "runs": sym.value == 2, "block_bodies": blk.value, "slabs": slabs.value,
                 "workgroups": wgs.value, "evaluated_pairs": ev.value}
 
+    def _info(self, fn, *args) -> dict:
+        sym, blk, slabs, wgs, ev = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_double()
+        check(fn(self._h, *args, C.byref(sym), C.byref(blk), C.byref(slabs), C.byref(wgs), C.byref(ev)))
+        return {"symmetric": bool(sym.value), "runs": sym.value == 2, "block_bodies": blk.value, "slabs": slabs.value,
+                "workgroups": wgs.value, "evaluated_pairs": ev.value}
+
+    def step_info_f64(self, n: int) -> dict:
+        """What nbody_step_f64 launches for n bodies."""
+        return self._info(self._lib.nbody_ctx_step_info_f64, n)
+
+    def square_info(self, n: int, nparts: int = 1) -> dict:
+        """What nbody_accel_square_part(.., nparts) launches for a block of n bodies against itself (one rank's own-block
+        pass of the sharded step: nparts = 2 when world > 1)."""
+        return self._info(self._lib.nbody_ctx_square_info, n, nparts)
+
     def step(self, x: torch.Tensor, a: torch.Tensor, v: torch.Tensor, steps: int = 1) -> None:
         n = x.shape[0]
         _check_f4(x), _check_f4(a, n), _check_f4(v, n)

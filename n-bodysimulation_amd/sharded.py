@@ -107,6 +107,35 @@ class TorchComm:
             rbuf[o:o + c].copy_(t)
 
 
+class NativeComm:
+    """The library's own RCCL communicator (nbody_comm_rccl_*: librccl loaded at run time, ncclAllGather in place and one
+    grouped ncclSend/ncclRecv per step, enqueued from C on the shard's communication stream — no Python in the step).
+    The 128-byte unique id is made by rank 0 and broadcast through the existing torch.distributed group (any backend):
+    that group stays the control plane (barriers, reductions of timings, gathering of results)."""
+
+    def __init__(self, device: torch.device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.nccl = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        self.native = True
+        lib = _lib.load()
+        uid = C.create_string_buffer(128)
+        if self.rank == 0:
+            check(lib.nbody_comm_rccl_unique_id(uid))
+        if self.world > 1:
+            box = [bytes(uid.raw)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            uid = C.create_string_buffer(box[0], 128)
+        self.struct = _lib.Comm()
+        check(lib.nbody_comm_rccl_create(C.byref(self.struct), self.rank, self.world, uid, device.index))
+
+    def close(self) -> None:
+        if getattr(self, "struct", None) is not None:
+            _lib.load().nbody_comm_rccl_destroy(C.byref(self.struct))
+            self.struct = None
+
+
 class _DeviceArray:
     """Zero-copy view of device memory the library owns, for torch.as_tensor."""
 
@@ -119,7 +148,9 @@ class ShardedSimulation:
 
     def __init__(self, bodies: np.ndarray, dt: float = _lib.DEFAULT_DT, eps2: float = _lib.DEFAULT_EPS2,
                  group=None, kernel: int = KERNEL_FAST, device: Optional[torch.device] = None, spatial_sort: bool = False,
-                 comm: Optional[TorchComm] = None, **kernel_opts):
+                 comm=None, **kernel_opts):
+        """comm: None or "torch" = the two collectives over torch.distributed (TorchComm; RCCL when the group's backend
+        is nccl); "native" = the library's own RCCL communicator (NativeComm); or a ready TorchComm / NativeComm."""
         from .engine import Context
         bodies = np.ascontiguousarray(bodies, np.float32)
         if bodies.ndim != 2 or bodies.shape[1] != 4:
@@ -130,13 +161,18 @@ class ShardedSimulation:
         self.perm = morton_order(bodies) if spatial_sort and len(bodies) else None
         if self.perm is not None:
             bodies = np.ascontiguousarray(bodies[self.perm])
-        self.comm = comm if comm is not None else TorchComm(group)
-        self.group, self.world, self.rank = self.comm.group, self.comm.world, self.comm.rank
-        self.n = bodies.shape[0]
         if device is None:
-            device = torch.device("cuda", self.rank % max(torch.cuda.device_count(), 1))
+            rank = dist.get_rank(group) if dist.is_initialized() else 0
+            device = torch.device("cuda", rank % max(torch.cuda.device_count(), 1))
         self.device = device
         torch.cuda.set_device(device)
+        if comm is None or comm == "torch":
+            comm = TorchComm(group)
+        elif comm == "native":
+            comm = NativeComm(device, group)
+        self.comm = comm
+        self.group, self.world, self.rank = self.comm.group, self.comm.world, self.comm.rank
+        self.n = bodies.shape[0]
         sym_waves, sym_bpl = kernel_opts.pop("sym_waves", 0), kernel_opts.pop("sym_bpl", 0)
         self.ctx = Context(device=device.index, dt=dt, eps2=eps2, kernel=kernel, **kernel_opts)
         if sym_waves or sym_bpl:
@@ -145,7 +181,7 @@ class ShardedSimulation:
         # the callbacks stay referenced for the life of the shard (ctypes does not keep them alive)
         self._cb_gather = _lib.ALL_GATHER_FN(self._on_all_gather)
         self._cb_exchange = _lib.EXCHANGE_FN(self._on_exchange)
-        self._comm_struct = _lib.Comm(None, self._cb_gather, self._cb_exchange)
+        self._comm_struct = self.comm.struct if getattr(self.comm, "native", False) else _lib.Comm(None, self._cb_gather, self._cb_exchange)
         self._h = C.c_void_p()
         self._error = None
         check(self._lib.nbody_shard_create(C.byref(self._h), self.ctx._h, self.rank, self.world, self.n, C.byref(self._comm_struct)))
@@ -194,6 +230,20 @@ class ShardedSimulation:
 
     def sync(self) -> None:
         self._check(self._lib.nbody_shard_sync(self._h))
+
+    def refresh_positions(self) -> None:
+        """One all-gather of positions without a step (phase 0 alone) and a sync: afterwards every rank's copy of every
+        block is the owner's current one. Diagnostic (bench.py's cross-rank check); call it with comm timing off."""
+        self._check(self._lib.nbody_shard_step_phase(self._h, 0))
+        self.sync()
+
+    def block_checksums(self) -> torch.Tensor:
+        """(world, 2) int64 on the device: for every rank's block of THIS rank's position array, the wrapping sum of the
+        float bit patterns and the wrapping sum of pattern * (word index + 1). Equal rows on every rank <=> the copies
+        are bit-identical (up to a 2^-64 accident)."""
+        bits = self.x[: self.world * self.shard].contiguous().view(torch.int32).to(torch.int64).view(self.world, self.shard * 4)
+        idx = torch.arange(1, self.shard * 4 + 1, device=bits.device, dtype=torch.int64)
+        return torch.stack([bits.sum(1), (bits * idx).sum(1)], dim=1)
 
     def comm_timing(self, enable: bool) -> None:
         self._check(self._lib.nbody_shard_comm_timing(self._h, 1 if enable else 0))
@@ -248,6 +298,8 @@ class ShardedSimulation:
             self._h = C.c_void_p()
             self.x = self.v = self.a = self._jbuf = self._rbuf = None
             self.ctx.close()            # after the shard: it launches on the context's stream
+            if getattr(self.comm, "native", False):
+                self.comm.close()
 
     def __del__(self):
         try:

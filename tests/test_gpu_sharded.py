@@ -316,15 +316,136 @@ def _run_bench(args, timeout=600):
     return json.loads(lines[0])
 
 
+def _torchrun(nproc, *bench_args):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(nproc), *bench_args]
+
+
+def _check_multi_gpu_line(line, world, n, comm, distinct):
+    """The self-certification fields of a multi-rank bench line (bench.py docstring: census, parity, cross-rank)."""
+    assert line["n_gpus"] == world and line["scaling"] == "strong" and line["config"]["n_bodies"] == n
+    assert abs(line["per_gpu_value"] * world - line["value"]) <= 1e-6 * line["value"]
+    r = line["config"]["rccl"]
+    assert r["world"] == world and r["ranks_seen"] and r["comm"] == comm and len(r["devices"]) == world
+    assert [d["rank"] for d in r["devices"]] == list(range(world)) and r["distinct_devices"] == distinct
+    assert all("MI3" in d["name"] or "Instinct" in d["name"] or d["name"] for d in r["devices"])
+    c = line["config"]["multi_gpu_check"]
+    assert c["finite"] and c["x_bitwise_equal_across_ranks"] and 0 <= c["max_rel_da"] <= c["tolerance"] == 5e-5
+    assert c["sampled_bodies_per_rank"] >= 1024 and c["steps_checked"] >= 1
+    assert line["config"]["comm_rank0"]["steps"] >= line["steps"]
+    assert line["value"] > 1e11 and 0 < line["roofline"]["frac"] < 1 and 0 < line["roofline"]["frac_evaluated"] <= line["roofline"]["frac"]
+    # the launch description is what the own-block pass really launches: block pairs (never "runs") when it is issued in parts
+    if world > 1 and line["config"]["launch"]["schedule"] == "symmetric":
+        assert line["config"]["launch"]["symmetric"] and not line["config"]["launch"]["runs"]
+
+
 def test_bench_two_ranks_over_gloo_on_one_gpu():
     """bench.py exactly as the driver launches it for N > 1 (python -m torch.distributed.run, one process per
     rank; the launcher starts before anything touches the GPU), rehearsed with 2 ranks sharing this box's one
-    GPU over gloo: one JSON line, n_gpus 2, strong scaling, the per-step communication report present."""
+    GPU over gloo: one JSON line, n_gpus 2, strong scaling, the census, the in-run parity of the sharded step against the
+    single-GPU kernel, the cross-rank bitwise check and the per-step communication report."""
+    line = _run_bench(_torchrun(2, "--backend", "gloo", "--bodies", "65536", "--steps", "3", "--warmup", "2", "--repeats", "2"))
+    assert line["steps"] == 3 and line["warmup"] == 2 and line["repeats"] == 2
+    _check_multi_gpu_line(line, 2, 65536, "torch", distinct=False)       # two ranks share the one GPU here
+    assert line["config"]["rccl"]["backend"] == "gloo"
+    assert "single_gpu_same_n" not in line                               # offline figure exists for N = 1048576 only
+
+
+@pytest.mark.parametrize("comm", ["torch", "native"])
+def test_bench_sharded_path_with_one_rank_over_rccl(comm):
+    """The multi-GPU code path of bench.py over REAL RCCL as far as one GPU allows without tricks: one rank
+    (--force-sharded): nccl process group, census (one distinct device), the sharded step through torch's RCCL ops or
+    through the library's own communicator, the in-run checks."""
+    line = _run_bench(_torchrun(1, "--force-sharded", "--comm", comm, "--bodies", "65536", "--steps", "3", "--warmup", "2",
+                                "--repeats", "2"))
+    _check_multi_gpu_line(line, 1, 65536, comm, distinct=True)
+    assert line["config"]["rccl"]["backend"] == "nccl"
+    assert line["config"]["multi_gpu_check"]["max_rel_da"] < 2e-5
+
+
+def _fake_hosts_work():
+    """Can RCCL run several ranks on this box's one GPU when every rank reports its own NCCL_HOSTID (tools/rccl_hostid_probe.py)?"""
+    import subprocess
+    import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    line = _run_bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                       "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
-                       "--bodies", "65536", "--steps", "3", "--warmup", "1", "--repeats", "2"])
-    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["repeats"] == 2
-    assert line["scaling"] == "strong" and line["config"]["n_bodies"] == 65536
-    assert line["config"]["comm_rank0"]["steps"] >= 3
-    assert line["value"] > 1e11 and 0 < line["roofline"]["frac"] < 1
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "tools", "rccl_hostid_probe.py")],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    return r.returncode == 0, (r.stdout + r.stderr)[-1500:]
+
+
+@pytest.fixture(scope="module")
+def fake_hosts():
+    ok, log = _fake_hosts_work()
+    if not ok:
+        pytest.skip("RCCL does not accept several ranks on one GPU here, even with distinct NCCL_HOSTIDs: " + log[-300:])
+    return True
+
+
+@pytest.mark.parametrize("comm,world", [("torch", 2), ("native", 2), ("native", 3)])
+def test_bench_multi_rank_over_real_rccl_on_one_gpu(fake_hosts, comm, world):
+    """REAL multi-rank RCCL on a 1-GPU box: every rank reports its own NCCL_HOSTID, so RCCL takes them for different hosts
+    (no "Duplicate GPU") and moves the data over its socket transport on the loopback interface. Slow transport, real
+    library: ncclCommInitRank with world > 1, the in-place ncclAllGather of positions and the grouped ncclSend/ncclRecv of
+    the J-side sums run for real — through torch.distributed (comm torch) and through nbody_comm_rccl_* (comm native) —
+    and the bench line certifies itself (parity vs the single-GPU kernel, bit-identical positions on all ranks)."""
+    line = _run_bench(_torchrun(world, "--fake-hosts", "--comm", comm, "--bodies", "49152", "--steps", "2", "--warmup", "2",
+                                "--repeats", "2"), timeout=900)
+    _check_multi_gpu_line(line, world, 49152, comm, distinct=False)
+    r = line["config"]["rccl"]
+    assert r["backend"] == "nccl" and r["fake_hosts"]
+    assert line["config"]["comm_rank0"]["all_gather_ms_avg"] > 0 and line["config"]["comm_rank0"]["exchange_ms_avg"] > 0
+
+
+def _nccl_fake_host_worker(rank, world, port, n, steps, comm, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["NCCL_HOSTID"] = f"nbody-test-host-{rank}"
+    os.environ["NCCL_SOCKET_IFNAME"] = "lo"
+    os.environ["NCCL_IB_DISABLE"] = "1"
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        import nbody_amd
+        x0 = nbody_amd.engine.seeded_bodies(n, 1, 77)
+        sim = nbody_amd.sharded.ShardedSimulation(x0, dt=0.01, eps2=0.002, device=dev, comm=comm, sym_waves=1, sym_bpl=2)
+        sim.comm_timing(True)
+        sim.step(steps)
+        x, v, a = sim.gather_state()
+        q.put((rank, x, v, a, sim.comm_report()))
+        sim.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("comm,world,n", [("torch", 2, 6000), ("native", 2, 6000), ("native", 4, 7001), ("torch", 3, 5001)])
+def test_sharded_simulation_over_real_rccl_on_one_gpu(nb, oracle, fake_hosts, comm, world, n):
+    """The product path (ShardedSimulation -> nbody_shard_* -> RCCL) with several ranks over REAL RCCL (fake host ids, see
+    above), symmetric schedule with the exchange of J-side sums, against the CPU oracle; identical positions on every rank."""
+    import torch.multiprocessing as mp
+    steps = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nccl_fake_host_worker, args=(r, world, port, n, steps, comm, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    x0 = nb.engine.seeded_bodies(n, 1, 77)
+    xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
+    oracle.step_jacobi(xo, ao, vo, dt=0.01, eps2=0.002, steps=steps)
+    for rank, x, v, a, rep in res:
+        assert np.abs(x - xo)[:, :3].max() <= 1e-6
+        assert np.abs(a - ao)[:, :3].max() / np.abs(ao[:, :3]).max() <= 1e-5
+        assert np.array_equal(x, res[0][1]) and np.array_equal(a, res[0][3])
+        assert rep["steps"] == steps and rep["schedule"] == "symmetric"
