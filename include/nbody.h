@@ -135,6 +135,15 @@ int nbody_ctx_set_symmetric_shape(nbody_ctx* ctx, int waves, int bodies_per_lane
  * nbody_ctx_set_symmetric_shape); 0: never; 1: always (bodies_per_lane 8 or 10). Same arithmetic, same determinism. */
 int nbody_ctx_set_symmetric_runs(nbody_ctx* ctx, int mode);
 
+/* The symmetric kernels keep one slab of partial sums per block of bodies (nb x n x 16 B: 412 MiB at N = 262144, 6.4 GiB at
+ * N = 1048576, growing as N^2/B). The launch-shape choice only uses a symmetric decomposition whose workspace fits a cap:
+ * min(96 GiB, half of the device memory that is free, `bytes` if non-zero); beyond it — or when the allocation itself fails —
+ * the step falls back to the next smaller footprint and finally to the one-sided kernel (<= 64 slabs, about 30 % slower at
+ * large N) instead of returning an error. nbody_accel_cross cuts its source run into pieces instead. bytes = 0: automatic.
+ * fail_above != 0 is a TEST hook: the shape choice ignores `bytes`, and every workspace allocation larger than `bytes` fails as
+ * if the device were out of memory (exercises the fallback path without exhausting a 288 GB device). */
+int nbody_ctx_set_workspace_limit(nbody_ctx* ctx, size_t bytes, int fail_above);
+
 /* Launch on this HIP stream (a hipStream_t passed as void*; NULL = the context's own stream). */
 int nbody_ctx_set_stream(nbody_ctx* ctx, void* hip_stream);
 

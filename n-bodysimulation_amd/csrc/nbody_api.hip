@@ -96,6 +96,11 @@ struct nbody_ctx {
     int num_cu = 256;
     void* slabs = nullptr;     // workspace: jsplit slabs of n_targets float4 (or double4)
     size_t slab_bytes = 0;
+    size_t ws_limit = 0;       // caller's cap on ONE workspace in bytes (nbody_ctx_set_workspace_limit); 0 = automatic
+    size_t ws_cap = (size_t)96 << 30;  // effective cap the shape choice honours: min(96 GiB, ws_limit, half of the device memory that
+                               // was free), lowered further whenever an allocation fails (the next choice then needs less)
+    bool ws_fail_above_limit = false;  // test hook: allocations above ws_limit are attempted and FAIL (out of memory) instead of
+                               // being avoided by the shape choice
     void* xslabs = nullptr;    // workspace of nbody_accel_cross (its own, so that a square evaluation issued in parts
     size_t xslab_bytes = 0;    // around cross launches keeps its partial sums)
     bool legacy_eps = false;     // strict kernel evaluates `+ EPS2` as the older snapshot does
@@ -202,7 +207,16 @@ struct SymShape {
 constexpr int kSymMinAuto = 12288;  // FAST switches to the symmetric kernel from this many bodies
 constexpr int kRunsMaxAuto = 160000; // the run-based variant is chosen automatically up to this many bodies
 constexpr int kSymMaxSlabs = 2048;
-constexpr size_t kSymMaxWorkspace = (size_t)96 << 30;  // one slab per block: beyond 96 GiB of partial sums the one-sided kernel takes over
+constexpr size_t kSymMaxWorkspace = (size_t)96 << 30;  // one slab per block: beyond 96 GiB of partial sums (or beyond half of the
+                                                       // free device memory, nbody_ctx::ws_cap) the one-sided kernel takes over
+
+// The (waves, bodies per lane) request that applies to the fp32 kernels: (4,6) is an fp64-only shape and counts as "auto" here.
+inline void fp32_shape_request(const nbody_ctx* c, int* waves, int* bpl)
+{
+    const bool f64_only = c->sym_waves == 4 && c->sym_bpl == 6;
+    *waves = f64_only ? 0 : c->sym_waves;
+    *bpl = f64_only ? 0 : c->sym_bpl;
+}
 
 // (waves, bodies per lane) instantiated below, largest block first
 const int kSymCand[][2] = {{4, 10}, {4, 8}, {2, 10}, {2, 8}, {1, 10}, {1, 8}, {2, 4}, {1, 4}, {1, 2}};
@@ -236,12 +250,14 @@ bool sym_resolve(const nbody_ctx* c, int n, SymShape* out)
 {
     int pick = -1;
     double best = 0.0;
+    int rw, rb;
+    fp32_shape_request(c, &rw, &rb);
     for (int k = 0; k < kSymCands; ++k) {
-        if ((c->sym_waves && kSymCand[k][0] != c->sym_waves) || (c->sym_bpl && kSymCand[k][1] != c->sym_bpl)) continue;
+        if ((rw && kSymCand[k][0] != rw) || (rb && kSymCand[k][1] != rb)) continue;
         const long B = 64L * kSymCand[k][0] * kSymCand[k][1];
         const long nb = (n + B - 1) / B;
         if (nb < 2 && pick >= 0) continue;
-        if (nb > kSymMaxSlabs || (size_t)nb * (size_t)n * sizeof(float4) > kSymMaxWorkspace) continue;
+        if (nb > kSymMaxSlabs || (size_t)nb * (size_t)n * sizeof(float4) > c->ws_cap) continue;
         const double cost = sym_cost(kSymCand[k][0], kSymCand[k][1], nb * (nb + 1) / 2, (double)nb * n * sizeof(float4), c->num_cu);
         if (pick < 0 || cost < best) { pick = k; best = cost; }
     }
@@ -253,7 +269,7 @@ bool sym_resolve(const nbody_ctx* c, int n, SymShape* out)
     y.nb = (n + y.block - 1) / y.block;
     y.grid = y.nb * (y.nb - 1) / 2 + y.nb;
     if (y.nb < 2 || y.nb > kSymMaxSlabs) return false;
-    if ((size_t)y.nb * (size_t)n * sizeof(float4) > kSymMaxWorkspace) return false;
+    if ((size_t)y.nb * (size_t)n * sizeof(float4) > c->ws_cap) return false;
     *out = y;
     return true;
 }
@@ -280,11 +296,14 @@ bool sym_resolve_cross(const nbody_ctx* c, int ni, int nj, SymShape* out, int* n
 {
     int pick = -1;
     double best = 0.0;
+    int rw, rb;
+    fp32_shape_request(c, &rw, &rb);
     for (int k = 0; k < kSymCands; ++k) {
-        if ((c->sym_waves && kSymCand[k][0] != c->sym_waves) || (c->sym_bpl && kSymCand[k][1] != c->sym_bpl)) continue;
+        if ((rw && kSymCand[k][0] != rw) || (rb && kSymCand[k][1] != rb)) continue;
         const long B = 64L * kSymCand[k][0] * kSymCand[k][1];
         const long bi = (ni + B - 1) / B, bj = (nj + B - 1) / B;
         if (bi > kSymMaxSlabs || bj > 4 * kSymMaxSlabs) continue;
+        if (((size_t)bj * (size_t)ni + (size_t)bi * (size_t)nj) * sizeof(float4) > c->ws_cap) continue;
         const double cost = sym_cost(kSymCand[k][0], kSymCand[k][1], bi * bj, ((double)bj * ni + (double)bi * nj) * sizeof(float4), c->num_cu);
         if (pick < 0 || cost < best) { pick = k; best = cost; }
     }
@@ -315,11 +334,14 @@ bool run_resolve(const nbody_ctx* c, int n, RunShape* out, double* cost_out)
     double best = 0.0;
     RunShape cand[2];
     static const int bpls[2] = {10, 8};
+    int rw, rb;
+    fp32_shape_request(c, &rw, &rb);
+    (void)rw;
     for (int k = 0; k < 2; ++k) {
         const int bpl = bpls[k];
-        if (c->sym_bpl && c->sym_bpl != bpl) continue;
+        if (rb && rb != bpl) continue;
         // measured: 10 bodies per lane is the better run shape below 49152 bodies, 8 (three waves per SIMD) from there
-        if (!c->sym_bpl && bpl != (n < 49152 ? 10 : 8)) continue;
+        if (!rb && bpl != (n < 49152 ? 10 : 8)) continue;
         RunShape y{};
         y.bpl = bpl;
         y.layout.bi = 64 * bpl;
@@ -335,7 +357,7 @@ bool run_resolve(const nbody_ctx* c, int n, RunShape* out, double* cost_out)
         y.layout.L = (int)L;
         y.nworkers = (int)((y.nunits + L - 1) / L);
         y.max_slabs = y.nbi + (int)((y.layout.ncht + L - 1) / L) + 2;
-        if ((size_t)y.max_slabs * (size_t)n * sizeof(float4) > kSymMaxWorkspace) continue;
+        if ((size_t)y.max_slabs * (size_t)n * sizeof(float4) > c->ws_cap) continue;
         const double unit = 64.0 * (41.33 * bpl + 22.6);
         const double deep = (double)((y.nworkers + simds - 1) / simds) * (double)L;          // units on the fullest SIMD
         const double slabs_avg = 0.5 * y.nbi + 0.5 * (double)y.layout.ncht / (double)L + 1.0;
@@ -353,7 +375,11 @@ bool run_resolve(const nbody_ctx* c, int n, RunShape* out, double* cost_out)
 // Does a square problem of n bodies go to the run-based variant rather than to block pairs?
 bool run_wanted(const nbody_ctx* c, int n, RunShape* out)
 {
-    if (c->sym_runs == 0 || c->sym_waves != 0) return false;
+    {
+        int rw, rb;
+        fp32_shape_request(c, &rw, &rb);
+        if (c->sym_runs == 0 || rw != 0) return false;
+    }
     if (!(c->kernel == NBODY_KERNEL_SYMMETRIC || (c->kernel == NBODY_KERNEL_FAST && n >= kSymMinAuto))) return false;
     double rc = 0.0;
     if (!run_resolve(c, n, out, &rc)) return false;
@@ -394,39 +420,56 @@ bool f64_sym_shape(const nbody_ctx* c, int n, int* W, int* BPL, int* nb_out)
     const int B = 64 * cand[pick][0] * cand[pick][1];
     const int nb = (n + B - 1) / B;
     if (nb < 2 || nb > kSymMaxSlabs) return false;
+    if ((size_t)nb * (size_t)n * sizeof(double4) > c->ws_cap) return false;
     *W = cand[pick][0];
     *BPL = cand[pick][1];
     *nb_out = nb;
     return true;
 }
 
-int ensure_xslabs(nbody_ctx* c, size_t bytes)
+// Recomputes the effective workspace cap from what the device has free right now (the context's own workspaces count as
+// available: they are released before a larger one is allocated). Needs the context's device to be current.
+void refresh_ws_cap(nbody_ctx* c)
 {
-    if (bytes <= c->xslab_bytes) return NBODY_OK;
-    if (c->xslabs) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(hipFree(c->xslabs));
-        c->xslabs = nullptr;
-        c->xslab_bytes = 0;
+    size_t cap = kSymMaxWorkspace;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const size_t avail = (free_b + c->slab_bytes + c->xslab_bytes) / 2;
+        if (avail < cap) cap = avail;
+    } else {
+        (void)hipGetLastError();
     }
-    HIP_TRY(hipMalloc(&c->xslabs, bytes));
-    c->xslab_bytes = bytes;
+    if (c->ws_limit && c->ws_limit < cap) cap = c->ws_limit;
+    if (c->ws_fail_above_limit) cap = kSymMaxWorkspace;   // test hook: let the shape choice ask for it, and the allocation fail
+    c->ws_cap = cap;
+}
+
+// Grows a workspace to `bytes`. An allocation that fails is not an error of the step: the cap is lowered below the request and
+// NBODY_ERR_NOMEM returned, so that the caller re-resolves its launch shape (a smaller symmetric footprint, finally the
+// one-sided kernel's <= 64 slabs) — only when nothing smaller exists does the failure reach the user.
+int grow_workspace(nbody_ctx* c, void** buf, size_t* have, size_t bytes)
+{
+    if (bytes <= *have) return NBODY_OK;
+    if (*buf) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipFree(*buf));
+        *buf = nullptr;
+        *have = 0;
+    }
+    hipError_t e = (c->ws_fail_above_limit && c->ws_limit && bytes > c->ws_limit) ? hipErrorOutOfMemory : hipMalloc(buf, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();   // the failed allocation must not surface at the next launch check
+        *buf = nullptr;
+        refresh_ws_cap(c);
+        if (c->ws_cap >= bytes) c->ws_cap = bytes - 1;
+        return fail(NBODY_ERR_NOMEM, "cannot allocate a workspace of %zu bytes: %s", bytes, hipGetErrorString(e));
+    }
+    *have = bytes;
     return NBODY_OK;
 }
 
-int ensure_slabs(nbody_ctx* c, size_t bytes)
-{
-    if (bytes <= c->slab_bytes) return NBODY_OK;
-    if (c->slabs) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(hipFree(c->slabs));
-        c->slabs = nullptr;
-        c->slab_bytes = 0;
-    }
-    HIP_TRY(hipMalloc(&c->slabs, bytes));
-    c->slab_bytes = bytes;
-    return NBODY_OK;
-}
+int ensure_xslabs(nbody_ctx* c, size_t bytes) { return grow_workspace(c, &c->xslabs, &c->xslab_bytes, bytes); }
+int ensure_slabs(nbody_ctx* c, size_t bytes) { return grow_workspace(c, &c->slabs, &c->slab_bytes, bytes); }
 
 template <class M, int TILE>
 void launch_lds(const nbk::ForceParams& p, dim3 grid, hipStream_t st)
@@ -607,6 +650,7 @@ int nbody_ctx_create(nbody_ctx** out, int device)
         return fail(NBODY_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
     }
     c->stream = c->own_stream;
+    refresh_ws_cap(c);   // half of what the device has free now bounds one workspace (re-read whenever a workspace grows)
     *out = c;
     return NBODY_OK;
 }
@@ -696,6 +740,16 @@ int nbody_ctx_set_symmetric_runs(nbody_ctx* c, int mode)
     return NBODY_OK;
 }
 
+int nbody_ctx_set_workspace_limit(nbody_ctx* c, size_t bytes, int fail_above)
+{
+    if (int rc = check_ctx(c)) return rc;
+    ON_DEVICE(c);
+    c->ws_limit = bytes;
+    c->ws_fail_above_limit = bytes != 0 && fail_above != 0;
+    refresh_ws_cap(c);
+    return NBODY_OK;
+}
+
 int nbody_ctx_set_stream(nbody_ctx* c, void* hip_stream)
 {
     if (int rc = check_ctx(c)) return rc;
@@ -708,12 +762,19 @@ int nbody_ctx_reserve(nbody_ctx* c, int n_targets)
     if (int rc = check_ctx(c)) return rc;
     if (n_targets < 0) return fail(NBODY_ERR_INVALID, "n_targets < 0");
     ON_DEVICE(c);
-    SymShape y{};
-    RunShape ry{};
-    size_t slabs = (size_t)resolve_shape(c, n_targets, n_targets).jsplit;
-    if (sym_wanted(c, n_targets, &y) && (size_t)y.nb > slabs) slabs = (size_t)y.nb;
-    if (run_wanted(c, n_targets, &ry) && (size_t)ry.max_slabs > slabs) slabs = (size_t)ry.max_slabs;
-    return ensure_slabs(c, slabs * (size_t)n_targets * sizeof(float4));
+    refresh_ws_cap(c);
+    for (int attempt = 0;; ++attempt) {
+        SymShape y{};
+        RunShape ry{};
+        size_t slabs = (size_t)resolve_shape(c, n_targets, n_targets).jsplit;
+        bool symmetric = false;
+        if (sym_wanted(c, n_targets, &y)) { symmetric = true; if ((size_t)y.nb > slabs) slabs = (size_t)y.nb; }
+        if (run_wanted(c, n_targets, &ry)) { symmetric = true; if ((size_t)ry.max_slabs > slabs) slabs = (size_t)ry.max_slabs; }
+        const int rc = ensure_slabs(c, slabs * (size_t)n_targets * sizeof(float4));
+        // out of memory for a symmetric footprint: the cap has been lowered, the next resolution needs less
+        if (rc == NBODY_ERR_NOMEM && symmetric && attempt < 16) continue;
+        return rc;
+    }
 }
 
 // Device-free view of the launch-shape logic (host tests; a context needs a GPU, this does not).
@@ -873,6 +934,19 @@ int accel_impl(nbody_ctx* c, const nbody_float4* d_bodies, nbody_float4* d_acc_o
 {
     const int nt = i1 - i0;
     ON_DEVICE(c);
+    // the symmetric decompositions need nb (or max_slabs) slabs of nt bodies: when that allocation fails the cap is lowered and
+    // the shape resolved again (a smaller footprint, finally the one-sided kernel)
+    for (int attempt = 0; attempt < 16; ++attempt) {
+        RunShape ry{};
+        SymShape y{};
+        size_t need = 0;
+        if (i0 == j0 && i1 == j1 && !wrap && run_wanted(c, nt, &ry)) need = (size_t)ry.max_slabs * nt * sizeof(float4);
+        else if (i0 == j0 && i1 == j1 && sym_wanted(c, nt, &y)) need = (size_t)y.nb * nt * sizeof(float4);
+        if (!need) break;
+        const int rc = ensure_slabs(c, need);
+        if (rc == NBODY_OK) break;
+        if (rc != NBODY_ERR_NOMEM) return rc;
+    }
     RunShape ry{};
     if (i0 == j0 && i1 == j1 && !wrap && run_wanted(c, nt, &ry)) {
         // a square block in runs of chunk units (16k ... 128k bodies)
@@ -965,11 +1039,18 @@ int nbody_accel_square_part(nbody_ctx* c, const nbody_float4* d_bodies, nbody_fl
     if (!d_bodies || !d_acc_out) return fail(NBODY_ERR_INVALID, "null device pointer");
     const int nt = i1 - i0;
     SymShape y{};
+    ON_DEVICE(c);
+    if (part == 0 && nparts > 1) {   // settle the shape (and its workspace) once, before the first part is issued
+        for (int attempt = 0; attempt < 16 && sym_wanted(c, nt, &y); ++attempt) {
+            const int rc = ensure_slabs(c, (size_t)y.nb * nt * sizeof(float4));
+            if (rc == NBODY_OK) break;
+            if (rc != NBODY_ERR_NOMEM) return rc;
+        }
+    }
     // One part, or no block-pair launch for this size / kernel id: the first part is the whole evaluation. (With several
     // parts the block-pair decomposition is used even where runs would be a few per cent faster: only a task list splits.)
     if (nparts == 1 || !sym_wanted(c, nt, &y))
         return part == 0 ? accel_impl(c, d_bodies, d_acc_out, i0, i1, i0, i1, 0, accumulate) : NBODY_OK;
-    ON_DEVICE(c);
     if (int rc = ensure_slabs(c, (size_t)y.nb * nt * sizeof(float4))) return rc;
     nbk::SymParams sp{};
     sym_square_params(&sp, reinterpret_cast<const float4*>(d_bodies), i0, nt, y, static_cast<float4*>(c->slabs), c->eps2);
@@ -1022,41 +1103,59 @@ int nbody_accel_cross(nbody_ctx* c, const nbody_float4* d_bodies, int n_total, n
         if (!accumulate_i) HIP_TRY(hipMemsetAsync(d_acc_i, 0, (size_t)ni * sizeof(float4), c->stream));
         return NBODY_OK;
     }
-    SymShape y{};
-    int nbj = 0;
-    if (!sym_resolve_cross(c, ni, count, &y, &nbj)) return fail(NBODY_ERR_CONFIG, "no symmetric kernel shape for %d x %d bodies", ni, count);
-    // workspace: nbj I-side slabs of ni bodies, then nbi J-side slabs of `count` bodies
-    const size_t islabs = (size_t)nbj * ni, jslabs = (size_t)y.nb * count;
-    if (int rc = ensure_xslabs(c, (islabs + jslabs) * sizeof(float4))) return rc;
-    nbk::SymParams sp{};
-    sp.x = reinterpret_cast<const float4*>(d_bodies);
-    sp.slabs_i = static_cast<float4*>(c->xslabs);
-    sp.slabs_j = static_cast<float4*>(c->xslabs) + islabs;
-    sp.ni = ni; sp.nj = count;
-    sp.i0 = i0; sp.j0 = j0;
-    sp.wrap = n_total;
-    sp.nbi = y.nb; sp.nbj = nbj;
-    sp.stride_i = ni; sp.stride_j = count;
-    sp.rect = 1;
-    sp.eps2 = c->eps2;
-    if (int rc = launch_sym(c, y, sp)) return rc;
-    nbk::ReduceParams r{};
-    r.out = reinterpret_cast<float4*>(d_acc_i);
-    r.slabs = sp.slabs_i;
-    r.nslab = nbj;
-    r.slab_stride = ni;
-    r.n = ni;
-    r.accumulate = accumulate_i ? 1 : 0;
-    nbk::reduce_slabs<<<(ni + nbk::kWG - 1) / nbk::kWG, nbk::kWG, 0, c->stream>>>(r);
-    HIP_TRY(hipGetLastError());
-    r.out = reinterpret_cast<float4*>(d_acc_j_out);
-    r.slabs = sp.slabs_j;
-    r.nslab = y.nb;
-    r.slab_stride = count;
-    r.n = count;
-    r.accumulate = 0;
-    nbk::reduce_slabs<<<(count + nbk::kWG - 1) / nbk::kWG, nbk::kWG, 0, c->stream>>>(r);
-    HIP_TRY(hipGetLastError());
+    // The workspace is nbj I-side slabs of ni bodies + nbi J-side slabs of the run. When it exceeds the cap (or cannot be
+    // allocated) the source run is cut into pieces that are evaluated one after the other, the I-side sums accumulating:
+    // same pair arithmetic, a smaller footprint per launch.
+    int pieces = 1;
+    for (;; pieces *= 2) {
+        const int per = (count + pieces - 1) / pieces;
+        SymShape y{};
+        int nbj = 0;
+        if (sym_resolve_cross(c, ni, per, &y, &nbj)) {
+            const int rc = ensure_xslabs(c, ((size_t)nbj * ni + (size_t)y.nb * per) * sizeof(float4));
+            if (rc == NBODY_OK) break;
+            if (rc != NBODY_ERR_NOMEM) return rc;
+        }
+        if (per <= 64) return fail(NBODY_ERR_NOMEM, "no workspace for the symmetric evaluation of %d x %d bodies even in pieces of %d sources", ni, count, per);
+    }
+    const int per = (count + pieces - 1) / pieces;
+    for (int q = 0, done = 0; done < count; ++q, done += per) {
+        const int cnt = count - done < per ? count - done : per;
+        SymShape y{};
+        int nbj = 0;
+        if (!sym_resolve_cross(c, ni, cnt, &y, &nbj)) return fail(NBODY_ERR_CONFIG, "no symmetric kernel shape for %d x %d bodies", ni, cnt);
+        const size_t islabs = (size_t)nbj * ni, jslabs = (size_t)y.nb * cnt;
+        if (int rc = ensure_xslabs(c, (islabs + jslabs) * sizeof(float4))) return rc;
+        nbk::SymParams sp{};
+        sp.x = reinterpret_cast<const float4*>(d_bodies);
+        sp.slabs_i = static_cast<float4*>(c->xslabs);
+        sp.slabs_j = static_cast<float4*>(c->xslabs) + islabs;
+        sp.ni = ni; sp.nj = cnt;
+        sp.i0 = i0; sp.j0 = (int)(((long)j0 + done) % n_total);
+        sp.wrap = n_total;
+        sp.nbi = y.nb; sp.nbj = nbj;
+        sp.stride_i = ni; sp.stride_j = cnt;
+        sp.rect = 1;
+        sp.eps2 = c->eps2;
+        if (int rc = launch_sym(c, y, sp)) return rc;
+        nbk::ReduceParams r{};
+        r.out = reinterpret_cast<float4*>(d_acc_i);
+        r.slabs = sp.slabs_i;
+        r.nslab = nbj;
+        r.slab_stride = ni;
+        r.n = ni;
+        r.accumulate = (accumulate_i || q > 0) ? 1 : 0;
+        nbk::reduce_slabs<<<(ni + nbk::kWG - 1) / nbk::kWG, nbk::kWG, 0, c->stream>>>(r);
+        HIP_TRY(hipGetLastError());
+        r.out = reinterpret_cast<float4*>(d_acc_j_out) + done;
+        r.slabs = sp.slabs_j;
+        r.nslab = y.nb;
+        r.slab_stride = cnt;
+        r.n = cnt;
+        r.accumulate = 0;
+        nbk::reduce_slabs<<<(cnt + nbk::kWG - 1) / nbk::kWG, nbk::kWG, 0, c->stream>>>(r);
+        HIP_TRY(hipGetLastError());
+    }
     return NBODY_OK;
 }
 
@@ -1093,8 +1192,15 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
     ON_DEVICE(c);
     SymShape y{};
     RunShape ry{};
-    const bool runs = run_wanted(c, n, &ry);
-    const bool sym = !runs && sym_wanted(c, n, &y);
+    bool runs = false, sym = false;
+    for (int attempt = 0;; ++attempt) {   // a symmetric footprint that cannot be allocated lowers the cap: resolve again
+        runs = run_wanted(c, n, &ry);
+        sym = !runs && sym_wanted(c, n, &y);
+        if (!runs && !sym) break;
+        const int rc = ensure_slabs(c, (runs ? (size_t)ry.max_slabs : (size_t)y.nb) * n * sizeof(float4));
+        if (rc == NBODY_OK) break;
+        if (rc != NBODY_ERR_NOMEM || attempt >= 16) return rc;
+    }
     const Shape s = resolve_shape(c, n, n);
     nbk::ForceParams p{};
     nbk::SymParams sp{};
@@ -1327,40 +1433,38 @@ int nbody_step_f64(nbody_ctx* c, nbody_double4* d_bodies, nbody_double4* d_accel
     q.a = reinterpret_cast<double4*>(d_accelerations);
     q.n = n;
     q.dt = dt;
-    {
+    // the symmetric rotation kernel in double; a footprint that cannot be allocated lowers the cap and the choice is made again
+    for (int attempt = 0; attempt < 4; ++attempt) {
         int W = 0, BPL = 0, nb = 0;
-        if (f64_sym_shape(c, n, &W, &BPL, &nb)) {
-            const int B = 64 * W * BPL;
-            (void)B;
-            {
-                if (int rc = ensure_slabs(c, (size_t)nb * n * sizeof(double4))) return rc;
-                nbk::SymParamsF64 sp{};
-                sp.x = reinterpret_cast<const double4*>(d_bodies);
-                sp.slabs_i = static_cast<double4*>(c->slabs);
-                sp.slabs_j = sp.slabs_i;
-                sp.ni = n; sp.nj = n; sp.i0 = 0; sp.j0 = 0; sp.wrap = 0;
-                sp.nbi = nb; sp.nbj = nb; sp.stride_i = n; sp.stride_j = n; sp.rect = 0;
-                sp.eps2 = eps2;
-                q.slabs = static_cast<const double4*>(c->slabs);
-                q.nslab = nb;
-                q.slab_stride = n;
-                const int grid = nb * (nb - 1) / 2 + nb;
-                for (int k = 0; k < steps; ++k) {
-                    if (int rc = time_mark(c)) return rc;
-                    switch (W * 100 + BPL) {
-                        case 408: nbk::force_sym<nbk::SymF64<8>, 4><<<grid, 256, 0, c->stream>>>(sp); break;
-                        case 406: nbk::force_sym<nbk::SymF64<6>, 4><<<grid, 256, 0, c->stream>>>(sp); break;
-                        case 204: nbk::force_sym<nbk::SymF64<4>, 2><<<grid, 128, 0, c->stream>>>(sp); break;
-                        default: nbk::force_sym<nbk::SymF64<2>, 1><<<grid, 64, 0, c->stream>>>(sp); break;
-                    }
-                    HIP_TRY(hipGetLastError());
-                    if (int rc = time_mark(c)) return rc;
-                    nbk::integrate_f64<<<(n + nbk::kWG - 1) / nbk::kWG, nbk::kWG, 0, c->stream>>>(q);
-                    HIP_TRY(hipGetLastError());
-                }
-                return NBODY_OK;
+        if (!f64_sym_shape(c, n, &W, &BPL, &nb)) break;   // the one-sided kernel below
+        const int arc = ensure_slabs(c, (size_t)nb * n * sizeof(double4));
+        if (arc == NBODY_ERR_NOMEM) continue;
+        if (arc) return arc;
+        nbk::SymParamsF64 sp{};
+        sp.x = reinterpret_cast<const double4*>(d_bodies);
+        sp.slabs_i = static_cast<double4*>(c->slabs);
+        sp.slabs_j = sp.slabs_i;
+        sp.ni = n; sp.nj = n; sp.i0 = 0; sp.j0 = 0; sp.wrap = 0;
+        sp.nbi = nb; sp.nbj = nb; sp.stride_i = n; sp.stride_j = n; sp.rect = 0;
+        sp.eps2 = eps2;
+        q.slabs = static_cast<const double4*>(c->slabs);
+        q.nslab = nb;
+        q.slab_stride = n;
+        const int grid = nb * (nb - 1) / 2 + nb;
+        for (int k = 0; k < steps; ++k) {
+            if (int rc = time_mark(c)) return rc;
+            switch (W * 100 + BPL) {
+                case 408: nbk::force_sym<nbk::SymF64<8>, 4><<<grid, 256, 0, c->stream>>>(sp); break;
+                case 406: nbk::force_sym<nbk::SymF64<6>, 4><<<grid, 256, 0, c->stream>>>(sp); break;
+                case 204: nbk::force_sym<nbk::SymF64<4>, 2><<<grid, 128, 0, c->stream>>>(sp); break;
+                default: nbk::force_sym<nbk::SymF64<2>, 1><<<grid, 64, 0, c->stream>>>(sp); break;
             }
+            HIP_TRY(hipGetLastError());
+            if (int rc = time_mark(c)) return rc;
+            nbk::integrate_f64<<<(n + nbk::kWG - 1) / nbk::kWG, nbk::kWG, 0, c->stream>>>(q);
+            HIP_TRY(hipGetLastError());
         }
+        return NBODY_OK;
     }
     // one-sided LDS-tiled kernel
     constexpr int BPL = 2, TILE = 512;

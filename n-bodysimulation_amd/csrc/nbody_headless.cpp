@@ -15,6 +15,8 @@
 // State files (--dump P / --load P): P.json {n, steps_done, dt, eps2} + P.x.f4 / P.v.f4 / P.a.f4,
 // raw little-endian float4[N] — exactly the three arrays main.cpp owns (main.cpp:232-241).
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -58,7 +60,7 @@ static bool read_file(const std::string& path, void* p, size_t bytes)
 
 int main(int argc, char** argv)
 {
-    int n = N_BODIES, steps = 10, kernel = NBODY_KERNEL_FAST, sync_each = 0, interactive = 0, json = 1, ngpu = 1;
+    int n = N_BODIES, steps = 10, kernel = NBODY_KERNEL_FAST, sync_each = 0, interactive = 0, json = 1, ngpu = 1, timeout_s = 900;
     bool f64 = false, force_shard = false;
     long steps_done = 0;
     float dt = DT, eps2 = EPS2;
@@ -79,6 +81,7 @@ int main(int argc, char** argv)
                      : k == "symmetric" ? NBODY_KERNEL_SYMMETRIC : NBODY_KERNEL_FAST;
         }
         else if (a == "--ngpu") ngpu = std::atoi(val());
+        else if (a == "--timeout") timeout_s = std::atoi(val());   // --ngpu: seconds before a stalled collective is given up (0 = wait for ever)
         else if (a == "--shard") force_shard = true;     // run through nbody_shard_* + RCCL even with one GPU
         else if (a == "--precision") { std::string q = val(); if (q != "f32" && q != "f64") die("--precision f32|f64"); f64 = q == "f64"; }
         else if (a == "--dump") dump = val();
@@ -87,7 +90,7 @@ int main(int argc, char** argv)
         else if (a == "--interactive") interactive = 1;
         else if (a == "--quiet") json = 0;
         else die("unknown option " + a + "\nusage: nbody_headless [--n N] [--steps K] [--dt f] [--eps2 f] [--init libc|ref|plummer] [--seed S]"
-                 " [--kernel fast|strict|onesided|symmetric] [--ngpu G] [--shard] [--precision f32|f64] [--dump P] [--load P] [--sync-each-step]"
+                 " [--kernel fast|strict|onesided|symmetric] [--ngpu G] [--timeout S] [--shard] [--precision f32|f64] [--dump P] [--load P] [--sync-each-step]"
                  " [--interactive]");
     }
     if (interactive) {
@@ -142,41 +145,101 @@ int main(int argc, char** argv)
         if (ngpu > ndev) die("--ngpu " + std::to_string(ngpu) + " but only " + std::to_string(ndev) + " device(s) visible");
         char uid[128];
         ok(nbody_comm_rccl_unique_id(uid));
+        // Every step that can fail LOCALLY (device, context, allocations) is taken before a collective one, and the ranks
+        // agree on success at a gate before entering it: a rank that failed never leaves its peers waiting inside
+        // ncclCommInitRank or the first all-gather. What can still stall (a collective itself) is bounded by a deadline
+        // on the main thread. Results are downloaded into per-rank buffers and merged after the join.
+        struct Gate {   // reusable barrier over the rank threads carrying a shared failure flag
+            std::mutex mu;
+            std::condition_variable cv;
+            int waiting = 0, generation = 0, parties;
+            bool failed = false;
+            explicit Gate(int n) : parties(n) {}
+            bool pass(bool ok_here)   // returns true when EVERY rank arrived with ok_here == true (now and at every earlier gate)
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                if (!ok_here) failed = true;
+                const int gen = generation;
+                if (++waiting == parties) { waiting = 0; ++generation; cv.notify_all(); }
+                else cv.wait(lk, [&] { return generation != gen; });
+                return !failed;
+            }
+        } gate(ngpu);
         std::vector<std::string> errors(ngpu);
         std::vector<double> rank_secs(ngpu, 0.0);
+        struct RankOut { int i0 = 0, i1 = 0; std::vector<nbody_float4> x, v, a; };
+        std::vector<RankOut> outs(ngpu);
+        std::mutex done_mu;
+        std::condition_variable done_cv;
+        int done = 0;
         std::printf("Starting the simulation...\n");
         auto rank_main = [&](int r) {
-            auto fail_here = [&](const char* what) { errors[r] = std::string(what) + ": " + nbody_last_error(); };
+            auto note = [&](const char* what) { if (errors[r].empty()) errors[r] = std::string(what) + ": " + nbody_last_error(); };
             nbody_ctx* ctx = nullptr;
             nbody_comm comm{};
             nbody_shard* sh = nullptr;
-            if (nbody_ctx_create(&ctx, r) != NBODY_OK) return fail_here("nbody_ctx_create");
-            if (nbody_ctx_set_params(ctx, dt, eps2) != NBODY_OK || nbody_ctx_set_kernel(ctx, kernel, 0, 0, 0) != NBODY_OK) return fail_here("context setup");
-            if (nbody_comm_rccl_create(&comm, r, ngpu, uid, r) != NBODY_OK) return fail_here("nbody_comm_rccl_create");
-            if (nbody_shard_create(&sh, ctx, r, ngpu, n, &comm) != NBODY_OK) return fail_here("nbody_shard_create");
-            if (nbody_shard_upload(sh, (const nbody_float4*)bodies) != NBODY_OK) return fail_here("nbody_shard_upload");
-            if (!load.empty() && nbody_shard_upload_velocity(sh, (const nbody_float4*)velocity) != NBODY_OK) return fail_here("nbody_shard_upload_velocity");
-            const auto t0 = std::chrono::steady_clock::now();
-            if (nbody_shard_step(sh, steps) != NBODY_OK || nbody_shard_sync(sh) != NBODY_OK) return fail_here("nbody_shard_step");
-            rank_secs[r] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            nbody_shard_plan_t plan;
-            nbody_shard_get_plan(sh, &plan);
-            std::vector<nbody_float4> x(plan.shard), v(plan.shard), a(plan.shard);
-            if (nbody_shard_download(sh, x.data(), v.data(), a.data()) != NBODY_OK) return fail_here("nbody_shard_download");
-            for (int i = plan.i0; i < plan.i1 && i < n; ++i) {   // the own block back into the whole-system host arrays
-                std::memcpy(&bodies[i], &x[i - plan.i0], sizeof(float4));
-                std::memcpy(&velocity[i], &v[i - plan.i0], sizeof(float4));
-                std::memcpy(&accelerations[i], &a[i - plan.i0], sizeof(float4));
+            bool good = true;
+            // 1. local: device, context
+            if (nbody_ctx_create(&ctx, r) != NBODY_OK) { note("nbody_ctx_create"); good = false; }
+            else if (nbody_ctx_set_params(ctx, dt, eps2) != NBODY_OK || nbody_ctx_set_kernel(ctx, kernel, 0, 0, 0) != NBODY_OK) { note("context setup"); good = false; }
+            if (gate.pass(good)) {
+                // 2. collective: the communicator (every rank enters, or none does)
+                if (nbody_comm_rccl_create(&comm, r, ngpu, uid, r) != NBODY_OK) { note("nbody_comm_rccl_create"); good = false; }
+                // 3. local: the shard's device arrays, the upload
+                if (good && nbody_shard_create(&sh, ctx, r, ngpu, n, &comm) != NBODY_OK) { note("nbody_shard_create"); good = false; }
+                if (good && nbody_shard_upload(sh, (const nbody_float4*)bodies) != NBODY_OK) { note("nbody_shard_upload"); good = false; }
+                if (good && !load.empty() && nbody_shard_upload_velocity(sh, (const nbody_float4*)velocity) != NBODY_OK) { note("nbody_shard_upload_velocity"); good = false; }
+                // every rank has read the shared host arrays before anybody steps (and nobody writes them before the join)
+                if (gate.pass(good)) {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    if (nbody_shard_step(sh, steps) != NBODY_OK || nbody_shard_sync(sh) != NBODY_OK) { note("nbody_shard_step"); good = false; }
+                    rank_secs[r] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    nbody_shard_plan_t plan;
+                    if (good && nbody_shard_get_plan(sh, &plan) == NBODY_OK) {
+                        RankOut& o = outs[r];
+                        o.i0 = plan.i0; o.i1 = plan.i1;
+                        o.x.resize(plan.shard); o.v.resize(plan.shard); o.a.resize(plan.shard);
+                        if (nbody_shard_download(sh, o.x.data(), o.v.data(), o.a.data()) != NBODY_OK) { note("nbody_shard_download"); good = false; }
+                    }
+                }
             }
-            nbody_shard_destroy(sh);
+            if (!good && errors[r].empty()) errors[r] = "skipped: another rank failed";
+            if (sh) nbody_shard_destroy(sh);
             nbody_comm_rccl_destroy(&comm);
-            nbody_ctx_destroy(ctx);
+            if (ctx) nbody_ctx_destroy(ctx);
+            std::lock_guard<std::mutex> lk(done_mu);
+            ++done;
+            done_cv.notify_all();
         };
         std::vector<std::thread> threads;
         for (int r = 0; r < ngpu; ++r) threads.emplace_back(rank_main, r);
+        {
+            std::unique_lock<std::mutex> lk(done_mu);
+            const bool finished = timeout_s <= 0 ? (done_cv.wait(lk, [&] { return done == ngpu; }), true)
+                                                 : done_cv.wait_for(lk, std::chrono::seconds(timeout_s), [&] { return done == ngpu; });
+            if (!finished) {   // a collective never completed: report and leave without unwinding the stuck threads
+                std::fprintf(stderr, "nbody_headless: %d of %d ranks still running after %d s (a collective stalled?); giving up\n",
+                             ngpu - done, ngpu, timeout_s);
+                for (int r = 0; r < ngpu; ++r)
+                    if (!errors[r].empty()) std::fprintf(stderr, "rank %d: %s\n", r, errors[r].c_str());
+                std::fflush(stderr);
+                std::_Exit(3);
+            }
+        }
         for (auto& t : threads) t.join();
+        bool any_error = false;
+        for (int r = 0; r < ngpu; ++r)
+            if (!errors[r].empty() && errors[r].rfind("skipped", 0) != 0) { std::cerr << "rank " << r << ": " << errors[r] << std::endl; any_error = true; }
+        for (int r = 0; r < ngpu && !any_error; ++r)
+            if (!errors[r].empty()) { std::cerr << "rank " << r << ": " << errors[r] << std::endl; any_error = true; }
+        if (any_error) return EXIT_FAILURE;
         for (int r = 0; r < ngpu; ++r) {
-            if (!errors[r].empty()) die("rank " + std::to_string(r) + ": " + errors[r]);
+            const RankOut& o = outs[r];
+            for (int i = o.i0; i < o.i1 && i < n; ++i) {   // the own blocks back into the whole-system host arrays
+                std::memcpy(&bodies[i], &o.x[i - o.i0], sizeof(float4));
+                std::memcpy(&velocity[i], &o.v[i - o.i0], sizeof(float4));
+                std::memcpy(&accelerations[i], &o.a[i - o.i0], sizeof(float4));
+            }
             if (rank_secs[r] > secs) secs = rank_secs[r];
         }
         std::printf("Simulation complete\n");

@@ -237,7 +237,8 @@ int nbody_shard_create(nbody_shard** out, nbody_ctx* ctx, int rank, int world, i
     e = hipDeviceSynchronize();  // the zero fills above ran on the null stream
     if (e != hipSuccess) return cleanup(nbody_fail(NBODY_ERR_HIP, "hipDeviceSynchronize failed: %s", hipGetErrorString(e)));
     // size the context's slab workspace once, for the largest launch of this rank
-    if (p.shard > 0) (void)nbody_ctx_reserve(ctx, p.shard);
+    if (p.shard > 0)
+        if (int rc = nbody_ctx_reserve(ctx, p.shard)) return cleanup(rc);
     *out = s;
     return NBODY_OK;
 }

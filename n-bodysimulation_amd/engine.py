@@ -96,6 +96,11 @@ class Context:
         """Run-based decomposition of the symmetric kernel: -1 where the cost estimate prefers it, 0 never, 1 always."""
         check(self._lib.nbody_ctx_set_symmetric_runs(self._h, mode))
 
+    def set_workspace_limit(self, nbytes: int = 0, fail_above: bool = False) -> None:
+        """Cap on one partial-sum workspace (0 = automatic: min(96 GiB, half of the free device memory)). Shapes that need
+        more are not chosen; the step falls back towards the one-sided kernel. fail_above=True is the test hook of nbody.h."""
+        check(self._lib.nbody_ctx_set_workspace_limit(self._h, nbytes, 1 if fail_above else 0))
+
     def set_stream(self, stream: Optional[torch.cuda.Stream]) -> None:
         self._stream = stream  # keep it alive
         check(self._lib.nbody_ctx_set_stream(self._h, C.c_void_p(stream.cuda_stream) if stream is not None else None))

@@ -144,7 +144,9 @@ def test_bench_defaults_name_the_baseline_configs():
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
     assert b.N_SINGLE == 262144 and b.N_MULTI == 1048576
-    assert b.default_workload(1, 0, "strong") == (262144, "weak")
+    assert b.default_workload(1, 0, "strong") == (262144, "strong")     # a point of the series it is compared with, never "weak" by default
+    assert b.default_workload(1, 0, "weak") == (262144, "weak")          # ... and the first point of the weak series
+    assert b.default_workload(1, 1048576, "strong") == (1048576, "strong")   # the same-N 1-GPU point of the strong series
     for g in (2, 4, 8):
         assert b.default_workload(g, 0, "strong") == (1048576, "strong")
     assert b.default_workload(8, 0, "weak") == (720896, "weak")

@@ -867,3 +867,111 @@ def test_config4_size_n1048576_on_one_gpu(nb, oracle):
     assert np.abs(arn - ag[i0:i1])[:, :3].max() / np.abs(ag[:, :3]).max() <= 4e-5
     truth = oracle.accel_range(x0, i0, i0 + 256, 0, n, eps2=0.002, f64acc=True)
     assert np.abs(arn[:256] - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 2e-5
+
+
+# ---- workspace cap and fallback (the symmetric kernels' O(N^2/B) partial-sum slabs) ---------------------------------
+
+def test_workspace_limit_steers_the_shape_choice_and_keeps_the_result(nb, oracle):
+    """nbody_ctx_set_workspace_limit: a symmetric decomposition whose slabs exceed the cap is not chosen — the step falls
+    back to a smaller footprint, finally to the one-sided kernel — and the answer stays within the fast tolerances."""
+    n = 20000
+    x0 = nb.engine.seeded_bodies(n, 1, 21)
+    truth = oracle.accel_range(x0, 0, 2048, 0, n, eps2=0.002, f64acc=True)
+    sim = nb.engine.Simulation(x0, dt=0.01, eps2=0.002)
+    free_choice = sim.ctx.step_info(n)
+    assert free_choice["symmetric"]
+    need = free_choice["slabs"] * n * 16
+    sim.run(1)
+    a_free = sim.state()[2]
+    for limit, want_symmetric in ((need // 2, None), (7 * n * 16, False), (1, False)):   # the largest block (2560 bodies) needs 8 slabs
+        s2 = nb.engine.Simulation(x0, dt=0.01, eps2=0.002)
+        s2.ctx.set_workspace_limit(limit)
+        info = s2.ctx.step_info(n)
+        assert info["slabs"] * n * 16 <= limit or not info["symmetric"]     # the one-sided kernel's <= 64 slabs are always allowed
+        if want_symmetric is not None:
+            assert info["symmetric"] == want_symmetric
+        s2.run(1)
+        a = s2.state()[2]
+        assert np.abs(a[:2048] - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 1e-5
+        assert np.abs(a - a_free)[:, :3].max() / np.abs(a_free[:, :3]).max() <= 1e-5
+        s2.ctx.set_workspace_limit(0)                                        # automatic again: the free choice is back
+        assert s2.ctx.step_info(n) == free_choice
+
+
+def test_failed_workspace_allocation_falls_back_instead_of_erroring(nb, oracle):
+    """The allocation itself fails (test hook: every workspace above the limit 'runs out of memory'): nbody_step,
+    nbody_accel_range, nbody_step_f64 and nbody_ctx_reserve lower the cap and re-resolve instead of returning an error."""
+    n = 20000
+    x0 = nb.engine.seeded_bodies(n, 1, 22)
+    truth = oracle.accel_range(x0, 0, 1024, 0, n, eps2=0.002, f64acc=True)
+    ctx = nb.engine.Context(dt=0.01, eps2=0.002)
+    ctx.set_workspace_limit(n * 16 * 3, fail_above=True)           # room for 3 slabs; no symmetric shape is refused up front
+    assert ctx.step_info(n)["symmetric"]                            # the planner still asks for one ...
+    x = torch.from_numpy(x0).cuda()
+    v, a = torch.zeros_like(x), torch.zeros_like(x)
+    ctx.step(x, a, v, 1)                                            # ... the allocation fails, the step falls back and succeeds
+    ctx.sync()
+    got = a.cpu().numpy()
+    assert np.abs(got[:1024] - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 1e-5
+    assert not ctx.step_info(n)["symmetric"]                        # the cap now sits below every symmetric footprint
+    out = torch.zeros_like(x)
+    ctx.accel_range(x, out, 0, n, 0, n)                             # the square block through nbody_accel_range: same
+    ctx.sync()
+    ctx.reserve(n)                                                  # and reserve() succeeds (one-sided footprint)
+    # fp64: the symmetric double kernel's slabs fail the same way, the one-sided double kernel takes over
+    ctx64 = nb.engine.Context(dt=0.01, eps2=0.002)
+    assert ctx64.step_info_f64(n)["symmetric"]
+    ctx64.set_workspace_limit(n * 32 * 70, fail_above=True)        # the one-sided f64 kernel's <= 64 slabs fit, 1 slab per block does not
+    xd = torch.from_numpy(x0.astype(np.float64)).cuda()
+    vd, ad = torch.zeros_like(xd), torch.zeros_like(xd)
+    ctx64.step_f64(xd, ad, vd, 0.01, 0.002, 1)
+    ctx64.sync()
+    t64 = oracle.accel_range_f64(x0.astype(np.float64), 0, 512, 0, n, eps2=0.002)
+    assert np.abs(ad.cpu().numpy()[:512] - t64)[:, :3].max() / np.abs(t64[:, :3]).max() <= 1e-12
+    assert np.abs(ad.cpu().numpy()[:1024] - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 1e-5
+    assert not ctx64.step_info_f64(n)["symmetric"]
+
+
+def test_accel_cross_in_pieces_under_a_workspace_limit(nb, oracle):
+    """nbody_accel_cross has no one-sided fallback: under a cap (or a failed allocation) it cuts the source run into pieces and
+    evaluates them one after the other. Same pairs, both sides' sums, within the fast tolerances of the uncut evaluation."""
+    n, i0, i1, j0, count = 9000, 1000, 3000, 7000, 5000            # the run wraps past the end
+    x0 = nb.engine.seeded_bodies(n, 0, 31)
+    x = torch.from_numpy(x0).cuda()
+    ref_i, ref_j = torch.zeros((i1 - i0, 4), device="cuda"), torch.zeros((count, 4), device="cuda")
+    ctx = nb.engine.Context()
+    ctx.accel_cross(x, ref_i, i0, i1, False, j0, count, ref_j)
+    ctx.sync()
+    for limit, hook in ((200_000, False), (300_000, True), (40_000, False)):
+        c2 = nb.engine.Context()
+        c2.set_workspace_limit(limit, fail_above=hook)
+        ai, aj = torch.full((i1 - i0, 4), 3.0, device="cuda"), torch.full((count, 4), 4.0, device="cuda")
+        c2.accel_cross(x, ai, i0, i1, False, j0, count, aj)
+        c2.sync()
+        for got, want in ((ai, ref_i), (aj, ref_j)):
+            g, w = got.cpu().numpy(), want.cpu().numpy()
+            assert np.abs(g - w)[:, :3].max() / np.abs(w[:, :3]).max() <= 1e-5
+            assert np.all(g[:, 3] == 0)
+    # an absurd cap is an error with a message, not a crash
+    c3 = nb.engine.Context()
+    c3.set_workspace_limit(64)
+    with pytest.raises(nb.NBodyError):
+        c3.accel_cross(x, ref_i, i0, i1, False, j0, count, ref_j)
+
+
+def test_fp64_only_shape_request_is_auto_for_fp32(nb, oracle):
+    """(4,6) is a double-precision block shape. Set on a context that then runs fp32 work it must not silently disable the
+    symmetric kernel (nor break nbody_accel_cross, which the sharded step depends on): it counts as 'auto' there."""
+    n = 20000
+    ctx = nb.engine.Context(dt=0.01, eps2=0.002)
+    auto = ctx.step_info(n)
+    ctx.set_symmetric_shape(4, 6)
+    assert ctx.step_info(n) == auto and auto["symmetric"]
+    assert ctx.step_info_f64(262144)["block_bodies"] == 64 * 4 * 6
+    x0 = nb.engine.seeded_bodies(6000, 0, 8)
+    x = torch.from_numpy(x0).cuda()
+    ai, aj = torch.zeros((2000, 4), device="cuda"), torch.zeros((3000, 4), device="cuda")
+    ctx.accel_cross(x, ai, 0, 2000, False, 2500, 3000, aj)
+    ctx.sync()
+    want = oracle.accel_range(x0, 0, 2000, 2500, 5500, eps2=0.002, f64acc=True)
+    assert np.abs(ai.cpu().numpy() - want)[:, :3].max() / np.abs(want[:, :3]).max() <= 1e-5
