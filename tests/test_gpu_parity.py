@@ -905,8 +905,9 @@ def test_failed_workspace_allocation_falls_back_instead_of_erroring(nb, oracle):
     x0 = nb.engine.seeded_bodies(n, 1, 22)
     truth = oracle.accel_range(x0, 0, 1024, 0, n, eps2=0.002, f64acc=True)
     ctx = nb.engine.Context(dt=0.01, eps2=0.002)
-    ctx.set_workspace_limit(n * 16 * 3, fail_above=True)           # room for 3 slabs; no symmetric shape is refused up front
-    assert ctx.step_info(n)["symmetric"]                            # the planner still asks for one ...
+    ctx.set_symmetric_shape(1, 2)                                   # 128-body blocks: 157 slabs
+    ctx.set_workspace_limit(n * 16 * 40, fail_above=True)          # room for 40 slabs (the one-sided kernel wants 32); nothing is refused up front
+    assert ctx.step_info(n)["symmetric"] and ctx.step_info(n)["slabs"] == 157   # the planner still asks for the symmetric shape ...
     x = torch.from_numpy(x0).cuda()
     v, a = torch.zeros_like(x), torch.zeros_like(x)
     ctx.step(x, a, v, 1)                                            # ... the allocation fails, the step falls back and succeeds
