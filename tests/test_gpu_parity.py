@@ -943,7 +943,7 @@ def test_accel_cross_in_pieces_under_a_workspace_limit(nb, oracle):
     ctx = nb.engine.Context()
     ctx.accel_cross(x, ref_i, i0, i1, False, j0, count, ref_j)
     ctx.sync()
-    for limit, hook in ((200_000, False), (300_000, True), (40_000, False)):
+    for limit, hook in ((100_000, False), (100_000, True), (40_000, False)):   # uncut: >= 110 KB; 2 pieces; 2+ after a failed allocation; 8
         c2 = nb.engine.Context()
         c2.set_workspace_limit(limit, fail_above=hook)
         ai, aj = torch.full((i1 - i0, 4), 3.0, device="cuda"), torch.full((count, 4), 4.0, device="cuda")
