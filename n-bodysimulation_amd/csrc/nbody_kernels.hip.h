@@ -25,6 +25,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 namespace nbk {
 
 constexpr int kWG = 256;  // threads per workgroup (4 wave64)
@@ -776,6 +778,267 @@ __global__ void __launch_bounds__(64) force_sym_run(const RunParams p)
             if (i < p.n) out_i[i] = t.acc(k);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// symmetric flavour in BALANCED runs — small and mid systems (a few thousand ... ~50k bodies)
+// ---------------------------------------------------------------------------------------
+//
+// The same unit list as force_sym_run (row I = the chunks from the I-block's own first chunk to the end of the system, rows end to
+// end), but cut at the granularity of ONE ROTATION STEP: a unit is 64 steps (4 row phases x 16 rotations), the list is T = 64 x units
+// steps long, and worker g (one wave, no LDS, no barrier) takes steps [g*L, (g+1)*L), L = ceil(T / workers) — every worker the same
+// number of steps, every SIMD the same number of resident workers. That is what N = 8192 (the reference's N_BODIES) needs: 2112
+// units over 1024 SIMDs is 2-or-3 units per SIMD when units are indivisible (a third of the machine idle), 66 steps per worker when
+// they are not.
+//   * A unit may be split between workers anywhere: each worker loads the chunk with the lane permutation of the row phase it
+//     starts in (lane l holds chunk body (l + 16*phase) & 63), runs its part of the 16 rotations of a phase through compile-time DPP
+//     steps guarded by wave-uniform range tests, and stores what the J bodies have collected SO FAR.
+//   * Partial sums go to per-chunk INBOXES: inbox[c] is a run of 1-KiB records (64 float4) — first `pmax` records for every row
+//     above the chunk's own block (record `piece` = which of the workers that share the unit wrote it; pieces that do not exist are
+//     never written and stay zero from the one-time clear of the workspace), then one record per worker that touched the chunk's
+//     own row (I-side sums). Every record has exactly one writer; nothing is atomic.
+//   * bal_reduce streams a chunk's records (no lookups: the count follows from two divisions), P waves taking every P-th record,
+//     adds them in record order and then over the waves — a fixed order, reproducible run to run — and integrates.
+
+struct BalLayout {
+    int bpl;       // stationary bodies per lane; an I-block is 64*bpl bodies
+    int nbi;       // I-blocks (rows)
+    int ncht;      // 64-body chunks in the system
+    int L;         // rotation steps per worker
+    int nworkers;
+    int pmax;      // records a unit's J-side sums can be spread over (workers sharing one unit)
+    int smax;      // records per inbox
+    int nsteps;    // 64 * units (< 2^31: checked on the host)
+};
+
+// units before row I
+__host__ __device__ inline int bal_row_prefix(int I, const BalLayout& y) { return I * y.ncht - y.bpl * (I * (I - 1) / 2); }
+
+// row of unit u: the largest I with bal_row_prefix(I) <= u
+__host__ __device__ inline int bal_row_of_unit(int u, const BalLayout& y)
+{
+    const float q = 2.0f * y.ncht + y.bpl;
+    int I = (int)((q - sqrtf(fmaxf(q * q - 8.0f * y.bpl * (float)u, 0.0f))) / (2.0f * y.bpl));
+    if (I < 0) I = 0;
+    if (I > y.nbi - 1) I = y.nbi - 1;
+    while (I < y.nbi - 1 && bal_row_prefix(I + 1, y) <= u) ++I;
+    while (I > 0 && bal_row_prefix(I, y) > u) --I;
+    return I;
+}
+
+// first and last worker with steps in row K
+__host__ __device__ inline void bal_row_workers(int K, const BalLayout& y, unsigned* gf, unsigned* gl)
+{
+    const unsigned row0 = (unsigned)bal_row_prefix(K, y), row1 = (unsigned)bal_row_prefix(K + 1, y);
+    *gf = (row0 << 6) / (unsigned)y.L;
+    *gl = ((row1 << 6) - 1u) / (unsigned)y.L;
+}
+
+// Host side: the layout for n bodies with `bpl` stationary bodies per lane and about `workers_target` workers (resident waves).
+// false when the decomposition does not apply (fewer than two chunks, step count beyond 2^31).
+inline bool bal_plan(int n, int bpl, int workers_target, BalLayout* out)
+{
+    if (n < 128 || bpl < 1 || workers_target < 1) return false;
+    BalLayout y{};
+    y.bpl = bpl;
+    y.ncht = (n + 63) / 64;
+    y.nbi = (n + 64 * bpl - 1) / (64 * bpl);
+    const long units = (long)y.nbi * y.ncht - (long)bpl * ((long)y.nbi * (y.nbi - 1) / 2);
+    if (units < 1 || units * 64 >= (1L << 31) - 64) return false;
+    y.nsteps = (int)(units * 64);
+    long L = (y.nsteps + (long)workers_target - 1) / workers_target;
+    if (L < 16) L = 16;   // at least one row phase per worker
+    y.L = (int)L;
+    y.nworkers = (int)((y.nsteps + L - 1) / L);
+    y.pmax = L >= 64 ? 2 : (int)(63 / L) + 2;
+    int smax = 1;
+    for (int K = 0; K < y.nbi; ++K) {
+        unsigned gf, gl;
+        bal_row_workers(K, y, &gf, &gl);
+        const int s = K * y.pmax + (int)(gl - gf + 1);
+        if (s > smax) smax = s;
+    }
+    y.smax = smax;
+    *out = y;
+    return true;
+}
+
+struct BalParams {
+    const float4* x;
+    float4* inbox;   // ncht * smax records of 64 float4, cleared once when the layout is set up
+    int n;
+    BalLayout y;
+    float eps2;
+};
+
+template <int S, bool SYM, class M>
+__device__ __forceinline__ void sym_step_if(M& t, const typename M::V4& bj, typename M::V4& aj, const int ta, const int tb)
+{
+    if (S >= ta && S < tb) sym_step<S, SYM>(t, bj, aj);  // ta, tb are wave-uniform: a scalar branch around the step
+}
+
+// rotations [ta, tb) of one row phase
+template <bool SYM, class M>
+__device__ __forceinline__ void sym_row_range(M& t, const typename M::V4& bj, typename M::V4& aj, const int ta, const int tb)
+{
+    if (ta == 0 && tb == 16) {   // a whole phase: straight-line code, the scheduler may overlap consecutive rotations
+        sym_row_pass<SYM>(t, bj, aj);
+        return;
+    }
+    sym_step_if<0, SYM>(t, bj, aj, ta, tb);  sym_step_if<1, SYM>(t, bj, aj, ta, tb);  sym_step_if<2, SYM>(t, bj, aj, ta, tb);
+    sym_step_if<3, SYM>(t, bj, aj, ta, tb);  sym_step_if<4, SYM>(t, bj, aj, ta, tb);  sym_step_if<5, SYM>(t, bj, aj, ta, tb);
+    sym_step_if<6, SYM>(t, bj, aj, ta, tb);  sym_step_if<7, SYM>(t, bj, aj, ta, tb);  sym_step_if<8, SYM>(t, bj, aj, ta, tb);
+    sym_step_if<9, SYM>(t, bj, aj, ta, tb);  sym_step_if<10, SYM>(t, bj, aj, ta, tb); sym_step_if<11, SYM>(t, bj, aj, ta, tb);
+    sym_step_if<12, SYM>(t, bj, aj, ta, tb); sym_step_if<13, SYM>(t, bj, aj, ta, tb); sym_step_if<14, SYM>(t, bj, aj, ta, tb);
+    sym_step_if<15, SYM>(t, bj, aj, ta, tb);
+}
+
+template <class M>
+__global__ void __launch_bounds__(64) force_sym_bal(const BalParams p)
+{
+    constexpr int BPL = M::BPL;
+    const int lane = threadIdx.x;
+    const int g = blockIdx.x;
+    const BalLayout& y = p.y;
+    int s = g * y.L;
+    const int s1 = (s + y.L < y.nsteps) ? s + y.L : y.nsteps;
+    if (s >= s1) return;
+    int I = bal_row_of_unit(s >> 6, y);
+    const int rot = ((lane + 16) & 63) << 2;
+    // chunk c as seen in row phase ph: lane l holds body (l + 16*ph) & 63 of the chunk
+    auto fetch = [&](int c, int ph) {
+        const int j = c * 64 + ((lane + 16 * ph) & 63);
+        return j < p.n ? p.x[j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    };
+    M t;
+    t.set_eps2(p.eps2);
+    for (; s < s1; ++I) {
+        const int row0 = bal_row_prefix(I, y), row1 = bal_row_prefix(I + 1, y);   // units of row I: [row0, row1)
+        const int seg1 = (row1 << 6) < s1 ? (row1 << 6) : s1;
+        const int ibase = I * (64 * BPL) + lane;
+#pragma unroll
+        for (int k = 0; k < BPL; ++k) {
+            const int i = ibase + k * 64;
+            t.set(k, i < p.n ? p.x[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        }
+        float4 nxt = fetch(I * BPL + ((s >> 6) - row0), (s & 63) >> 4);
+        while (s < seg1) {
+            const int u = s >> 6;
+            const int c = I * BPL + (u - row0);
+            const int q0 = s & 63;
+            const int uend = ((u + 1) << 6) < seg1 ? ((u + 1) << 6) : seg1;
+            const int q1 = q0 + (uend - s);              // this worker does steps [q0, q1) of the unit, 0 <= q0 < q1 <= 64
+            const int ph0 = q0 >> 4, ph1 = (q1 - 1) >> 4;
+            float4 bj = nxt;
+            if (uend < seg1) nxt = fetch(c + 1, 0);     // the next unit of this worker starts at its first step
+            float4 aj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (c < (I + 1) * BPL) {  // a chunk of the block itself: both orders of every pair occur, one side each
+                for (int ph = ph0; ph <= ph1; ++ph) {
+                    const int ta = ph == ph0 ? (q0 & 15) : 0, tb = ph == ph1 ? ((q1 - 1) & 15) + 1 : 16;
+                    sym_row_range<false>(t, bj, aj, ta, tb);
+                    if (ph < ph1) { bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot); bj.w = next_row(bj.w, rot); }
+                }
+            } else {
+                for (int ph = ph0; ph <= ph1; ++ph) {
+                    const int ta = ph == ph0 ? (q0 & 15) : 0, tb = ph == ph1 ? ((q1 - 1) & 15) + 1 : 16;
+                    sym_row_range<true>(t, bj, aj, ta, tb);
+                    if (ph < ph1) {
+                        bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot); bj.w = next_row(bj.w, rot);
+                        aj.x = next_row(aj.x, rot); aj.y = next_row(aj.y, rot); aj.z = next_row(aj.z, rot);
+                    }
+                }
+                // what the chunk's bodies collected from this worker's part of the unit: lane l holds body (l + 16*ph1) & 63;
+                // record = row I's run of the chunk's inbox, piece = this worker's ordinal among the workers sharing the unit
+                const int piece = g - (int)(((unsigned)u << 6) / (unsigned)y.L);
+                float4* const out_j = p.inbox + ((size_t)c * y.smax + I * y.pmax + piece) * 64;
+                aj.w = 0.0f;
+                out_j[(lane + 16 * ph1) & 63] = aj;
+            }
+            s = uend;
+        }
+        // I-side sums: one record in the inbox of each of the block's chunks, after the J-side runs of the rows above
+        unsigned gf, gl;
+        bal_row_workers(I, y, &gf, &gl);
+        const int rec = I * y.pmax + (g - (int)gf);
+#pragma unroll
+        for (int k = 0; k < BPL; ++k) {
+            const int c = I * BPL + k;
+            if (c < y.ncht) p.inbox[((size_t)c * y.smax + rec) * 64 + lane] = t.acc(k);
+        }
+    }
+}
+
+// Sum of one 64-body chunk's inbox (one workgroup of 64*P threads per chunk; wave p takes records p, p + P, ...), then either the
+// integrate (x, v, a in place) or the accelerations alone. Order: records ascending within a wave, then the P waves in order —
+// fixed, so results are reproducible run to run.
+struct BalReduceParams {
+    const float4* inbox;
+    BalLayout y;
+    int n;
+    // integrate (mode 0): x, v, a of the bodies; accelerations only (mode 1): a (+= when accumulate)
+    float4* x;
+    float4* v;
+    float4* a;
+    float dt;
+    int mode;
+    int accumulate;
+};
+
+template <int P>
+__global__ void __launch_bounds__(64 * P) bal_reduce(const BalReduceParams p)
+{
+#pragma clang fp contract(off)
+    __shared__ float4 sh[P][64];
+    const BalLayout& y = p.y;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = blockIdx.x;
+    const int K = c / y.bpl;
+    unsigned gf, gl;
+    bal_row_workers(K, y, &gf, &gl);
+    const int nrec = K * y.pmax + (int)(gl - gf + 1);
+    const float4* const box = p.inbox + (size_t)c * y.smax * 64 + lane;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    int r = w;
+    for (; r + 7 * P < nrec; r += 8 * P) {   // eight independent loads in flight, added in record order
+        float4 q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q[e] = box[(size_t)(r + e * P) * 64];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { acc.x += q[e].x; acc.y += q[e].y; acc.z += q[e].z; }
+    }
+    for (; r < nrec; r += P) {
+        const float4 q = box[(size_t)r * 64];
+        acc.x += q.x; acc.y += q.y; acc.z += q.z;
+    }
+    sh[w][lane] = acc;
+    __syncthreads();
+    if (w != 0) return;
+    float4 a = sh[0][lane];
+#pragma unroll
+    for (int q = 1; q < P; ++q) {
+        const float4 b = sh[q][lane];
+        a.x += b.x; a.y += b.y; a.z += b.z;
+    }
+    a.w = 0.0f;
+    const int i = c * 64 + lane;
+    if (i >= p.n) return;
+    if (p.mode == 1) {
+        if (p.accumulate) {
+            const float4 o = p.a[i];
+            a.x += o.x; a.y += o.y; a.z += o.z;
+        }
+        p.a[i] = a;
+        return;
+    }
+    p.a[i] = a;
+    float4 v = p.v[i];
+    float4 x = p.x[i];
+    const float hdt = 0.5f * p.dt;
+    v.x += hdt * a.x; v.y += hdt * a.y; v.z += hdt * a.z;
+    x.x += p.dt * v.x; x.y += p.dt * v.y; x.z += p.dt * v.z;
+    p.v[i] = v;
+    p.x[i] = x;
 }
 
 // ---------------------------------------------------------------------------------------

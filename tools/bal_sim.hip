@@ -1,0 +1,129 @@
+// tools/bal_sim.hip — HOST emulation of the balanced-run decomposition (nbk::force_sym_bal + nbk::bal_reduce): same plan
+// (nbk::bal_plan), same control flow and index arithmetic, lanes played by a loop, pair "forces" replaced by a random antisymmetric
+// weight w(i, j) = -w(j, i). Checks, without a GPU, that every ordered pair reaches its body exactly once through the partial-sum
+// areas and the reducer's lookups: sum_j w(i, j) for every body i. Needs no device (hipcc compiles it, nothing is launched).
+//   hipcc -O2 -std=c++17 --offload-arch=gfx950 -I n-bodysimulation_amd/csrc tools/bal_sim.hip -o build/bal_sim && build/bal_sim
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "nbody_kernels.hip.h"
+
+static double wgt(int i, int j)   // antisymmetric pseudo-random weight, exactly representable sums are not needed (double)
+{
+    if (i == j) return 0.0;
+    const int a = i < j ? i : j, b = i < j ? j : i;
+    uint64_t z = (uint64_t)a * 1000003ull + (uint64_t)b + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const double v = (double)(z >> 11) * (1.0 / 9007199254740992.0) + 0.25;
+    return i < j ? v : -v;
+}
+
+static bool run_case(int n, int bpl, int workers, int P)
+{
+    nbk::BalLayout y{};
+    if (!nbk::bal_plan(n, bpl, workers, &y)) { printf("n=%d bpl=%d: no plan\n", n, bpl); return true; }
+    const int BI = 64 * bpl;
+    std::vector<double> inbox((size_t)y.ncht * y.smax * 64, 0.0);     // cleared once, as the library does
+    std::vector<char> written((size_t)y.ncht * y.smax, 0);
+    long steps_done = 0;
+    for (int g = 0; g < y.nworkers; ++g) {   // force_sym_bal, one worker
+        int s = g * y.L;
+        const int s1 = (s + y.L < y.nsteps) ? s + y.L : y.nsteps;
+        int I = nbk::bal_row_of_unit(s >> 6, y);
+        if (!(nbk::bal_row_prefix(I, y) <= (s >> 6) && (s >> 6) < nbk::bal_row_prefix(I + 1, y))) { printf("bad row of unit\n"); return false; }
+        for (; s < s1; ++I) {
+            const int row0 = nbk::bal_row_prefix(I, y), row1 = nbk::bal_row_prefix(I + 1, y);
+            const int seg1 = (row1 << 6) < s1 ? (row1 << 6) : s1;
+            std::vector<double> acc((size_t)BI, 0.0);   // acc[k*64 + lane]
+            while (s < seg1) {
+                const int u = s >> 6, c = I * bpl + (u - row0), q0 = s & 63;
+                const int uend = ((u + 1) << 6) < seg1 ? ((u + 1) << 6) : seg1;
+                const int q1 = q0 + (uend - s), ph0 = q0 >> 4, ph1 = (q1 - 1) >> 4;
+                const bool diag = c < (I + 1) * bpl;
+                std::vector<double> aj(64, 0.0);   // indexed by chunk body (what the moving lanes carry with them)
+                for (int ph = ph0; ph <= ph1; ++ph) {
+                    const int ta = ph == ph0 ? (q0 & 15) : 0, tb = ph == ph1 ? ((q1 - 1) & 15) + 1 : 16;
+                    for (int t = ta; t < tb; ++t) {
+                        ++steps_done;
+                        for (int lane = 0; lane < 64; ++lane) {
+                            // lane `lane` meets the J body held by lane src of its 16-lane row; that lane holds chunk body (src + 16*ph) & 63
+                            const int src = (lane & 48) | ((lane + t) & 15);
+                            const int jb = (src + 16 * ph) & 63, j = c * 64 + jb;
+                            for (int k = 0; k < bpl; ++k) {
+                                const int i = I * BI + k * 64 + lane;
+                                if (i >= n || j >= n) continue;   // massless padding: exact zeros
+                                acc[(size_t)k * 64 + lane] += wgt(i, j);
+                                if (!diag) aj[jb] += wgt(j, i);
+                            }
+                        }
+                    }
+                }
+                if (!diag) {
+                    const int piece = g - (int)(((unsigned)u << 6) / (unsigned)y.L);
+                    if (piece < 0 || piece >= y.pmax) { printf("piece %d out of range (pmax %d)\n", piece, y.pmax); return false; }
+                    const size_t rec = (size_t)c * y.smax + I * y.pmax + piece;
+                    if (written[rec]++) { printf("record written twice\n"); return false; }
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int body = (lane + 16 * ph1) & 63;
+                        inbox[rec * 64 + body] = aj[body];
+                    }
+                }
+                s = uend;
+            }
+            unsigned gf, gl;
+            nbk::bal_row_workers(I, y, &gf, &gl);
+            if ((unsigned)g < gf || (unsigned)g > gl) { printf("worker outside its row's range\n"); return false; }
+            const int recI = I * y.pmax + (g - (int)gf);
+            if (recI >= y.smax) { printf("smax overflow\n"); return false; }
+            for (int k = 0; k < bpl; ++k) {
+                const int c = I * bpl + k;
+                if (c >= y.ncht) continue;
+                if (written[(size_t)c * y.smax + recI]++) { printf("I record written twice\n"); return false; }
+                for (int lane = 0; lane < 64; ++lane) inbox[((size_t)c * y.smax + recI) * 64 + lane] = acc[(size_t)k * 64 + lane];
+            }
+        }
+    }
+    if (steps_done != y.nsteps) { printf("steps %ld != %d\n", steps_done, y.nsteps); return false; }
+    // bal_reduce
+    double worst = 0.0;
+    long terms = 0;
+    for (int c = 0; c < y.ncht; ++c) {
+        const int K = c / bpl;
+        unsigned gf, gl;
+        nbk::bal_row_workers(K, y, &gf, &gl);
+        const int nrec = K * y.pmax + (int)(gl - gf + 1);
+        for (int r = K * y.pmax; r < nrec; ++r)
+            if (!written[(size_t)c * y.smax + r]) { printf("I-side record %d of chunk %d never written\n", r, c); return false; }
+        for (int lane = 0; lane < 64; ++lane) {
+            const int i = c * 64 + lane;
+            if (i >= n) continue;
+            double sum = 0.0;
+            for (int w = 0; w < P; ++w)
+                for (int r = w; r < nrec; r += P) { sum += inbox[((size_t)c * y.smax + r) * 64 + lane]; ++terms; }
+            double want = 0.0;
+            for (int j = 0; j < n; ++j) want += wgt(i, j);
+            const double e = std::fabs(sum - want);
+            if (!(e <= 1e-9)) { printf("n=%d bpl=%d W=%d: body %d got %.12g want %.12g\n", n, bpl, workers, i, sum, want); return false; }
+            if (e > worst) worst = e;
+        }
+    }
+    printf("n=%5d bpl=%2d workers=%5d (L=%4d, %5d used, pmax %d smax %3d) P=%d: ok, %.1f records/body, worst %.2g\n", n, bpl, workers, y.L,
+           y.nworkers, y.pmax, y.smax, P, (double)terms / n, worst);
+    return true;
+}
+
+int main()
+{
+    bool ok = true;
+    for (int n : {128, 129, 200, 777, 1000, 1024, 2050, 3001})
+        for (int bpl : {2, 4, 8, 10})
+            for (int workers : {1, 7, 64, 500, 2048, 100000})
+                ok = ok && run_case(n, bpl, workers, n % 2 ? 4 : 8);
+    printf(ok ? "ALL OK\n" : "FAILED\n");
+    return ok ? 0 : 1;
+}

@@ -70,6 +70,127 @@ static float median_ms(const std::function<void()>& f, int reps)
     return ts[ts.size() / 2];
 }
 
+// ---- measured alternative (round 3): ROW-ACCUMULATING tasks --------------------------------------------------------------------
+// One workgroup keeps its I-block in registers across R consecutive J blocks: the I-side sums are written once per R block pairs
+// (slab[J0], J0 = the group's first J block), the J-side sums once per J block as before. Partial-sum bytes per launch: about
+// (1 + 1/R)/2 of the shipped kernel's. Task list: row I has ceil((nb-1-I)/R) groups, then the nb diagonal blocks; row_of[] holds
+// the first task of every row (host-made). Same pair arithmetic and rotation scheme as nbk::force_sym (rect == 0 only).
+struct RowsParams {
+    const float4* x;
+    float4* slabs;
+    const int* row_first_task;  // nb entries + total
+    int n, nb, stride, R, npair_tasks;
+    float eps2;
+};
+
+template <class M, int W>
+__global__ void __launch_bounds__(64 * W, 1) force_sym_rows(const RowsParams p)
+{
+    using namespace nbk;
+    constexpr int BPL = M::BPL;
+    constexpr int B = 64 * W * BPL;
+    constexpr int NCH = B / 64;
+    __shared__ float4 sh[B];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int task = blockIdx.x;
+    int I, J0, J1;
+    const bool diag = task >= p.npair_tasks;
+    if (diag) {
+        I = J0 = task - p.npair_tasks;
+        J1 = J0 + 1;
+    } else {
+        int lo = 0, hi = p.nb - 2;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (p.row_first_task[mid] <= task) lo = mid; else hi = mid - 1;
+        }
+        I = lo;
+        J0 = I + 1 + (task - p.row_first_task[I]) * p.R;
+        J1 = J0 + p.R < p.nb ? J0 + p.R : p.nb;
+    }
+    M t;
+    t.set_eps2(p.eps2);
+    const int ibase = I * B + w * (64 * BPL) + lane;
+#pragma unroll
+    for (int k = 0; k < BPL; ++k) {
+        const int i = ibase + k * 64;
+        t.set(k, i < p.n ? p.x[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    }
+    const int rot = ((lane + 16) & 63) << 2;
+    for (int J = J0; J < J1; ++J) {
+        const int jbase = J * B + lane;
+        auto fetch = [&](int c) {
+            const int j = jbase + c * 64;
+            return j < p.n ? p.x[j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        };
+        if (!diag) {
+            if (J != J0) __syncthreads();   // the previous block's J-side sums have been stored
+#pragma unroll
+            for (int r = 0; r < BPL; ++r) sh[r * (64 * W) + tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            __syncthreads();
+        }
+        int c = w * BPL;
+        float4 nxt = fetch(c);
+        for (int q = 0; q < NCH; ++q) {
+            float4 bj = nxt;
+            const int cn = (c + 1 == NCH) ? 0 : c + 1;
+            if (q + 1 < NCH) nxt = fetch(cn);
+            if (diag) {
+                float4 aj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                for (int ph = 0; ph < 4; ++ph) {
+                    sym_row_pass<false>(t, bj, aj);
+                    bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot); bj.w = next_row(bj.w, rot);
+                }
+            } else {
+                float4 aj = sh[c * 64 + lane];
+                for (int ph = 0; ph < 4; ++ph) {
+                    sym_row_pass<true>(t, bj, aj);
+                    bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot); bj.w = next_row(bj.w, rot);
+                    aj.x = next_row(aj.x, rot); aj.y = next_row(aj.y, rot); aj.z = next_row(aj.z, rot);
+                }
+                sh[c * 64 + lane] = aj;
+                __syncthreads();
+            }
+            c = cn;
+        }
+        if (!diag) {
+            float4* const out_j = p.slabs + (size_t)I * p.stride;
+            for (int e = tid; e < B; e += 64 * W) {
+                const int j = J * B + e;
+                if (j < p.n) { float4 a = sh[e]; a.w = 0.0f; out_j[j] = a; }
+            }
+        }
+    }
+    float4* const out_i = p.slabs + (size_t)J0 * p.stride;   // diagonal: J0 == I
+#pragma unroll
+    for (int k = 0; k < BPL; ++k) {
+        const int i = ibase + k * 64;
+        if (i < p.n) out_i[i] = t.acc(k);
+    }
+}
+
+// body i of block I: slabs 0 .. I (J-side sums of the rows above, the diagonal), then every R-th slab from I + 1 (one per group)
+__global__ void __launch_bounds__(256) reduce_rows(float4* out, const float4* slabs, int n, int nb, int B, int R)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int I = i / B;
+    float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll 8
+    for (int s = 0; s <= I; ++s) {
+        const float4 q = slabs[(size_t)s * n + i];
+        a.x += q.x; a.y += q.y; a.z += q.z;
+    }
+#pragma unroll 8
+    for (int s = I + 1; s < nb; s += R) {
+        const float4 q = slabs[(size_t)s * n + i];
+        a.x += q.x; a.y += q.y; a.z += q.z;
+    }
+    out[i] = a;
+}
+
 struct SymVariant {
     std::string name;
     int B;
@@ -220,6 +341,60 @@ int main(int argc, char** argv)
         printf("%-34s %8.3f ms (force alone %.3f)  %.3e pairs/s  %.1f%% of 157.3 TF | vs one-sided max diff %.3g of max|a|, nonfinite %ld, vs truth %.3g | one-sided again %.3f ms\n",
                v.name.c_str(), ms, ms_force, pairs / ms * 1e3, 20 * pairs / ms * 1e3 / 157.3e12 * 100, dmax / scale, bad, err_vs_truth(a_sym), t2);
         fflush(stdout);
+    }
+    // ---- row-accumulating tasks (R consecutive J blocks per workgroup): bytes of partial sums and time against the shipped shape
+    {
+        constexpr int W = 4, BPL = 10, B = 64 * W * BPL;
+        const int nb = (n + B - 1) / B;
+        if (nb >= 2 && nb <= max_slabs) {
+            nbk::SymParams sp{};
+            sp.x = dx; sp.slabs_i = slabs; sp.slabs_j = slabs; sp.ni = n; sp.nj = n; sp.i0 = 0; sp.j0 = 0; sp.wrap = 0; sp.nbi = nb; sp.nbj = nb;
+            sp.stride_i = n; sp.stride_j = n; sp.rect = 0; sp.eps2 = eps2;
+            const int grid0 = nb * (nb - 1) / 2 + nb;
+            auto shipped = [&] {
+                nbk::force_sym<nbk::SymPacked<BPL>, W><<<grid0, 64 * W>>>(sp);
+                reduce(da_ref, nb);
+            };
+            printf("row-accumulating tasks, B=%d, nb=%d: shipped (R=1) %d tasks, %.1f MB of partial sums written + read again\n", B, nb, grid0,
+                   (double)nb * n * 16 / 1e6);
+            for (int R : {1, 2, 3, 4, 8}) {
+                std::vector<int> first(nb + 1, 0);
+                int tasks = 0;
+                for (int I = 0; I < nb; ++I) { first[I] = tasks; tasks += (nb - 1 - I + R - 1) / R; }
+                first[nb] = tasks;
+                int* d_first;
+                CK(hipMalloc(&d_first, (nb + 1) * sizeof(int)));
+                CK(hipMemcpy(d_first, first.data(), (nb + 1) * sizeof(int), hipMemcpyHostToDevice));
+                RowsParams rp{};
+                rp.x = dx; rp.slabs = slabs; rp.row_first_task = d_first; rp.n = n; rp.nb = nb; rp.stride = n; rp.R = R; rp.npair_tasks = tasks; rp.eps2 = eps2;
+                const int grid = tasks + nb;
+                auto rows = [&] {
+                    force_sym_rows<nbk::SymPacked<BPL>, W><<<grid, 64 * W>>>(rp);
+                    reduce_rows<<<(n + 255) / 256, 256>>>(da_sym, slabs, n, nb, B, R);
+                };
+                CK(hipMemset(slabs, 0xff, (size_t)nb * n * 16));
+                rows();
+                CK(hipGetLastError());
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(a_sym.data(), da_sym, (size_t)n * 16, hipMemcpyDeviceToHost));
+                double dmax = 0, scale = 0;
+                long bad = 0;
+                for (int i = 0; i < n; ++i) scale = std::max({scale, (double)std::fabs(a_ref[i].x), (double)std::fabs(a_ref[i].y), (double)std::fabs(a_ref[i].z)});
+                for (int i = 0; i < n; ++i) {
+                    const double e = std::max({std::fabs((double)a_ref[i].x - a_sym[i].x), std::fabs((double)a_ref[i].y - a_sym[i].y),
+                                               std::fabs((double)a_ref[i].z - a_sym[i].z)});
+                    if (!(e <= 1e30)) ++bad; else dmax = std::max(dmax, e);
+                }
+                // partial sums actually written: per body of block I: I + 1 + ceil((nb-1-I)/R) slabs
+                double bytes = 0;
+                for (int I = 0; I < nb; ++I) bytes += (double)std::min(B, n - I * B) * (I + 1 + (nb - 1 - I + R - 1) / R) * 16;
+                const float ms_a = median_ms(shipped, reps), ms_r = median_ms(rows, reps), ms_a2 = median_ms(shipped, reps), ms_r2 = median_ms(rows, reps);
+                printf("  R=%d: %5d tasks, partial sums %.1f MB (%.0f%% of shipped) | rows %.3f / %.3f ms, shipped interleaved %.3f / %.3f ms | vs one-sided %.3g of max|a|, nonfinite %ld, vs truth %.3g\n",
+                       R, grid, bytes / 1e6, bytes / ((double)nb * n * 16) * 100, ms_r, ms_r2, ms_a, ms_a2, dmax / scale, bad, err_vs_truth(a_sym));
+                fflush(stdout);
+                CK(hipFree(d_first));
+            }
+        }
     }
     return 0;
 }
