@@ -129,10 +129,13 @@ int nbody_ctx_set_kernel(nbody_ctx* ctx, int kernel, int tile, int bodies_per_la
  * cheapest by the library's cost estimate, see nbody_plan_symmetric). The fp64 step takes (4,6) (4,8) (2,4) (1,2). */
 int nbody_ctx_set_symmetric_shape(nbody_ctx* ctx, int waves, int bodies_per_lane);
 
-/* The symmetric kernel has a second decomposition for mid-size systems (about 16k ... 128k bodies), where whole block
- * pairs are too coarse a unit for 1024 SIMDs: independent waves take RUNS of (I-block, one 64-body chunk) units. mode -1
- * (default): used where the library's cost estimate prefers it (never when a waves count was set through
- * nbody_ctx_set_symmetric_shape); 0: never; 1: always (bodies_per_lane 8 or 10). Same arithmetic, same determinism. */
+/* The symmetric kernel has two more decompositions for small and mid-size systems, where whole block pairs are too coarse a
+ * unit for 1024 SIMDs. UNIT RUNS (about 45k ... 160k bodies): independent waves take runs of (I-block, one 64-body chunk)
+ * units. BALANCED RUNS (about 7k ... 45k bodies, the reference's N_BODIES = 8192 among them): the same unit list cut at the
+ * granularity of one rotation step, so that every resident wave gets the same number of steps; partial sums go to per-chunk
+ * inboxes that one kernel sums and integrates. mode -1 (default): each is used where measurements prefer it (never when a waves
+ * count was set through nbody_ctx_set_symmetric_shape); 0: never; 1: unit runs always (bodies_per_lane 8 or 10); 2: balanced
+ * runs always (bodies_per_lane 2, 4, 8 or 10; 0 = by size). Same pair arithmetic, same run-to-run reproducibility. */
 int nbody_ctx_set_symmetric_runs(nbody_ctx* ctx, int mode);
 
 /* The symmetric kernels keep one slab of partial sums per block of bodies (nb x n x 16 B: 412 MiB at N = 262144, 6.4 GiB at
@@ -370,7 +373,7 @@ int nbody_ctx_launch_info(nbody_ctx* ctx, int n_targets, int n_sources, int* jsp
                           int* lds_bytes);
 
 /* What nbody_step() does for n bodies: symmetric = 1 when the symmetric kernel runs on block pairs, 2 when it runs in
- * runs of chunk units, 0 for the one-sided kernel; block_bodies = bodies
+ * runs of chunk units, 3 in balanced runs of rotation steps (slabs = records per inbox), 0 for the one-sided kernel; block_bodies = bodies
  * per block (symmetric) or per workgroup (one-sided); slabs = partial-sum slabs the integrate adds;
  * workgroups = grid size; evaluated_pairs = pair evaluations per step (n*n one-sided; about n*n/2 plus
  * the diagonal blocks symmetric — the interactions applied are n*n either way). Any out pointer may be NULL. */

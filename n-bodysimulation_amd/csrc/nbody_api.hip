@@ -99,6 +99,7 @@ struct nbody_ctx {
     size_t ws_limit = 0;       // caller's cap on ONE workspace in bytes (nbody_ctx_set_workspace_limit); 0 = automatic
     size_t ws_cap = (size_t)96 << 30;  // effective cap the shape choice honours: min(96 GiB, ws_limit, half of the device memory that
                                // was free), lowered further whenever an allocation fails (the next choice then needs less)
+    unsigned long long ws_tag = 0;     // which balanced-run layout the `slabs` workspace is cleared for (0 = none: any other user of it)
     bool ws_fail_above_limit = false;  // test hook: allocations above ws_limit are attempted and FAIL (out of memory) instead of
                                // being avoided by the shape choice
     void* xslabs = nullptr;    // workspace of nbody_accel_cross (its own, so that a square evaluation issued in parts
@@ -378,7 +379,7 @@ bool run_wanted(const nbody_ctx* c, int n, RunShape* out)
     {
         int rw, rb;
         fp32_shape_request(c, &rw, &rb);
-        if (c->sym_runs == 0 || rw != 0) return false;
+        if (c->sym_runs == 0 || c->sym_runs == 2 || rw != 0) return false;
     }
     if (!(c->kernel == NBODY_KERNEL_SYMMETRIC || (c->kernel == NBODY_KERNEL_FAST && n >= kSymMinAuto))) return false;
     double rc = 0.0;
@@ -392,6 +393,42 @@ bool run_wanted(const nbody_ctx* c, int n, RunShape* out)
     if (!sym_resolve(c, n, &y)) return true;
     const double bc = sym_cost(y.waves, y.bpl, (long)y.nb * (y.nb + 1) / 2, (double)y.nb * n * sizeof(float4), c->num_cu);
     return rc < 1.03 * bc;
+}
+
+// The BALANCED-run variant (nbk::force_sym_bal): workers of equal step counts, per-chunk inboxes, streaming reducer.
+struct BalShape {
+    nbk::BalLayout y;
+    size_t bytes;   // inbox workspace
+};
+
+constexpr int kBalMinAuto = 8192;    // FAST: balanced runs from this many bodies (below: the one-sided kernel) ...
+constexpr int kBalMaxAuto = 45056;   // ... up to this many (above: unit runs / block pairs). Measured: profiles/r03_balbench_*.txt
+constexpr int kBalWavesPerSimd = 2, kBalWavesPerGroup = 4, kBalReduceWaves = 8;
+
+bool bal_resolve(const nbody_ctx* c, int n, BalShape* out)
+{
+    int rw, rb;
+    fp32_shape_request(c, &rw, &rb);
+    if (rw != 0) return false;                       // a waves-per-workgroup request means block pairs
+    int bpl = rb;
+    if (bpl == 0) bpl = n < 10240 ? 4 : (n < 20480 ? 8 : 10);   // measured best per size (tools/balbench.hip)
+    if (bpl != 2 && bpl != 4 && bpl != 8 && bpl != 10) return false;
+    BalShape b{};
+    if (!nbk::bal_plan(n, bpl, 4 * c->num_cu * kBalWavesPerSimd, kBalWavesPerGroup, &b.y)) return false;
+    if (b.y.pmax > 5) return false;                  // the reducer holds at most five pieces of a unit
+    b.bytes = (size_t)b.y.ncht * (size_t)b.y.smax * 64 * sizeof(float4);
+    if (b.bytes > c->ws_cap) return false;
+    *out = b;
+    return true;
+}
+
+// Does a square problem of n bodies go to the balanced-run variant?
+bool bal_wanted(const nbody_ctx* c, int n, BalShape* out)
+{
+    if (c->sym_runs == 0 || c->sym_runs == 1) return false;
+    if (c->sym_runs == 2) return (c->kernel == NBODY_KERNEL_FAST || c->kernel == NBODY_KERNEL_SYMMETRIC) && bal_resolve(c, n, out);
+    if (c->kernel != NBODY_KERNEL_FAST || n < kBalMinAuto || n > kBalMaxAuto) return false;
+    return bal_resolve(c, n, out);
 }
 
 // Does a square problem of n bodies (targets == sources) go to the symmetric kernel?
@@ -469,7 +506,30 @@ int grow_workspace(nbody_ctx* c, void** buf, size_t* have, size_t bytes)
 }
 
 int ensure_xslabs(nbody_ctx* c, size_t bytes) { return grow_workspace(c, &c->xslabs, &c->xslab_bytes, bytes); }
-int ensure_slabs(nbody_ctx* c, size_t bytes) { return grow_workspace(c, &c->slabs, &c->slab_bytes, bytes); }
+int ensure_slabs(nbody_ctx* c, size_t bytes)
+{
+    c->ws_tag = 0;   // whoever asks for slabs overwrites what a balanced-run layout keeps cleared
+    return grow_workspace(c, &c->slabs, &c->slab_bytes, bytes);
+}
+
+// The inbox workspace of a balanced-run layout: records of unit pieces that do not exist are never written and must read as zero,
+// so the workspace is cleared once per layout (and again whenever anything else has used it in between).
+int ensure_inbox(nbody_ctx* c, const BalShape& b)
+{
+    const nbk::BalLayout& y = b.y;
+    unsigned long long tag = 0x9E3779B97F4A7C15ull;
+    for (unsigned long long v : {(unsigned long long)y.bpl, (unsigned long long)y.ncht, (unsigned long long)y.L, (unsigned long long)y.smax,
+                                 (unsigned long long)y.pmax, (unsigned long long)y.wv, (unsigned long long)y.nsteps})
+        tag = (tag ^ v) * 0xBF58476D1CE4E5B9ull + 1;
+    const void* before = c->slabs;
+    const size_t had = c->slab_bytes;
+    if (int rc = grow_workspace(c, &c->slabs, &c->slab_bytes, b.bytes)) { c->ws_tag = 0; return rc; }
+    if (c->slabs != before || c->slab_bytes != had || c->ws_tag != tag) {
+        HIP_TRY(hipMemsetAsync(c->slabs, 0, b.bytes, c->stream));
+        c->ws_tag = tag;
+    }
+    return NBODY_OK;
+}
 
 template <class M, int TILE>
 void launch_lds(const nbk::ForceParams& p, dim3 grid, hipStream_t st)
@@ -560,6 +620,35 @@ int launch_run(nbody_ctx* c, const RunShape& y, const nbk::RunParams& p)
     return time_mark(c);
 }
 
+template <class M>
+void launch_bal_t(const nbk::BalParams& p, hipStream_t st)
+{
+    const int groups = (p.y.nworkers + kBalWavesPerGroup - 1) / kBalWavesPerGroup;
+    nbk::force_sym_bal<M, kBalWavesPerGroup><<<groups, 64 * kBalWavesPerGroup, 0, st>>>(p);
+}
+
+int launch_bal(nbody_ctx* c, const nbk::BalParams& p, bool timed)
+{
+    if (timed) if (int rc = time_mark(c)) return rc;
+    switch (p.y.bpl) {
+        case 2: launch_bal_t<nbk::SymPacked<2>>(p, c->stream); break;
+        case 4: launch_bal_t<nbk::SymPacked<4>>(p, c->stream); break;
+        case 8: launch_bal_t<nbk::SymPacked<8>>(p, c->stream); break;
+        case 10: launch_bal_t<nbk::SymPacked<10>>(p, c->stream); break;
+        default: return fail(NBODY_ERR_CONFIG, "no balanced-run kernel for bodies_per_lane=%d", p.y.bpl);
+    }
+    HIP_TRY(hipGetLastError());
+    if (timed) return time_mark(c);
+    return NBODY_OK;
+}
+
+int launch_bal_reduce(nbody_ctx* c, const nbk::BalReduceParams& r)
+{
+    nbk::bal_reduce<kBalReduceWaves><<<r.y.ncht, 64 * kBalReduceWaves, 0, c->stream>>>(r);
+    HIP_TRY(hipGetLastError());
+    return NBODY_OK;
+}
+
 void run_params(nbk::RunParams* rp, const float4* x, int n, const RunShape& y, float4* slabs, float eps2)
 {
     *rp = nbk::RunParams{};
@@ -607,7 +696,7 @@ const char* nbody_last_error(void) { return g_err; }
 
 const char* nbody_version(void)
 {
-    return "nbody_hip 0.2 gfx950 fast=symmetric-dpp(w4,bpl10)|onesided-lds-packed(bpl4,tile2048,u8) strict=ieee-seq f64=symmetric-dpp(w4,bpl6)|lds";
+    return "nbody_hip 0.3 gfx950 fast=symmetric-dpp(w4,bpl10)|symmetric-balanced-runs(7k-45k)|onesided-lds-packed(bpl4,tile2048,u8) strict=ieee-seq f64=symmetric-dpp(w4,bpl6)|lds";
 }
 
 int nbody_device_count(int* count)
@@ -735,7 +824,7 @@ int nbody_ctx_set_symmetric_shape(nbody_ctx* c, int waves, int bodies_per_lane)
 int nbody_ctx_set_symmetric_runs(nbody_ctx* c, int mode)
 {
     if (int rc = check_ctx(c)) return rc;
-    if (mode < -1 || mode > 1) return fail(NBODY_ERR_CONFIG, "runs mode must be -1 (auto), 0 (never) or 1 (always)");
+    if (mode < -1 || mode > 2) return fail(NBODY_ERR_CONFIG, "runs mode must be -1 (auto), 0 (never), 1 (unit runs always) or 2 (balanced runs always)");
     c->sym_runs = mode;
     return NBODY_OK;
 }
@@ -764,6 +853,12 @@ int nbody_ctx_reserve(nbody_ctx* c, int n_targets)
     ON_DEVICE(c);
     refresh_ws_cap(c);
     for (int attempt = 0;; ++attempt) {
+        BalShape by{};
+        if (bal_wanted(c, n_targets, &by)) {
+            const int rc = ensure_inbox(c, by);
+            if (rc == NBODY_ERR_NOMEM && attempt < 16) continue;
+            return rc;
+        }
         SymShape y{};
         RunShape ry{};
         size_t slabs = (size_t)resolve_shape(c, n_targets, n_targets).jsplit;
@@ -827,6 +922,13 @@ int nbody_ctx_launch_info(nbody_ctx* c, int n_targets, int n_sources, int* jspli
     if (n_targets < 0 || n_sources < 0) return fail(NBODY_ERR_INVALID, "negative size");
     SymShape y{};
     RunShape ry{};
+    BalShape by{};
+    if (n_targets == n_sources && bal_wanted(c, n_targets, &by)) {
+        if (jsplit) *jsplit = by.y.smax;
+        if (blocks) *blocks = (by.y.nworkers + kBalWavesPerGroup - 1) / kBalWavesPerGroup;
+        if (lds_bytes) *lds_bytes = kBalWavesPerGroup * 64 * by.y.bpl * (int)sizeof(float4);
+        return NBODY_OK;
+    }
     if (n_targets == n_sources && run_wanted(c, n_targets, &ry)) {
         if (jsplit) *jsplit = ry.max_slabs;
         if (blocks) *blocks = ry.nworkers;
@@ -853,6 +955,15 @@ int nbody_ctx_step_info(nbody_ctx* c, int n, int* symmetric, int* block_bodies, 
     if (n < 0) return fail(NBODY_ERR_INVALID, "negative size");
     SymShape y{};
     RunShape ry{};
+    BalShape by{};
+    if (bal_wanted(c, n, &by)) {
+        if (symmetric) *symmetric = 3;  // symmetric, in balanced runs of rotation steps
+        if (block_bodies) *block_bodies = 64 * by.y.bpl;
+        if (slabs) *slabs = by.y.smax;
+        if (workgroups) *workgroups = (by.y.nworkers + kBalWavesPerGroup - 1) / kBalWavesPerGroup;
+        if (evaluated_pairs) *evaluated_pairs = (double)by.y.nsteps * 64.0 * by.y.bpl;
+        return NBODY_OK;
+    }
     if (run_wanted(c, n, &ry)) {
         if (symmetric) *symmetric = 2;  // symmetric, in runs of chunk units
         if (block_bodies) *block_bodies = ry.layout.bi;
@@ -937,6 +1048,27 @@ int accel_impl(nbody_ctx* c, const nbody_float4* d_bodies, nbody_float4* d_acc_o
     // the symmetric decompositions need nb (or max_slabs) slabs of nt bodies: when that allocation fails the cap is lowered and
     // the shape resolved again (a smaller footprint, finally the one-sided kernel)
     for (int attempt = 0; attempt < 16; ++attempt) {
+        BalShape by{};
+        if (i0 == j0 && i1 == j1 && !wrap && bal_wanted(c, nt, &by)) {
+            const int rc = ensure_inbox(c, by);
+            if (rc == NBODY_ERR_NOMEM) continue;
+            if (rc) return rc;
+            nbk::BalParams bp{};
+            bp.x = reinterpret_cast<const float4*>(d_bodies) + i0;
+            bp.inbox = static_cast<float4*>(c->slabs);
+            bp.n = nt;
+            bp.y = by.y;
+            bp.eps2 = c->eps2;
+            if (int rc2 = launch_bal(c, bp, true)) return rc2;
+            nbk::BalReduceParams rp{};
+            rp.inbox = static_cast<const float4*>(c->slabs);
+            rp.y = by.y;
+            rp.n = nt;
+            rp.a = reinterpret_cast<float4*>(d_acc_out);
+            rp.mode = 1;
+            rp.accumulate = accumulate ? 1 : 0;
+            return launch_bal_reduce(c, rp);
+        }
         RunShape ry{};
         SymShape y{};
         size_t need = 0;
@@ -1192,8 +1324,16 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
     ON_DEVICE(c);
     SymShape y{};
     RunShape ry{};
-    bool runs = false, sym = false;
+    BalShape by{};
+    bool bal = false, runs = false, sym = false;
     for (int attempt = 0;; ++attempt) {   // a symmetric footprint that cannot be allocated lowers the cap: resolve again
+        bal = bal_wanted(c, n, &by);
+        if (bal) {
+            const int rc = ensure_inbox(c, by);
+            if (rc == NBODY_OK) break;
+            if (rc != NBODY_ERR_NOMEM || attempt >= 16) return rc;
+            continue;
+        }
         runs = run_wanted(c, n, &ry);
         sym = !runs && sym_wanted(c, n, &y);
         if (!runs && !sym) break;
@@ -1211,7 +1351,21 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
     q.a = reinterpret_cast<float4*>(d_accelerations);
     q.n = n;
     q.dt = c->dt;
-    if (runs) {
+    nbk::BalParams bp{};
+    nbk::BalReduceParams brp{};
+    if (bal) {
+        bp.x = reinterpret_cast<const float4*>(d_bodies);
+        bp.inbox = static_cast<float4*>(c->slabs);
+        bp.n = n;
+        bp.y = by.y;
+        bp.eps2 = c->eps2;
+        brp.inbox = static_cast<const float4*>(c->slabs);
+        brp.y = by.y;
+        brp.n = n;
+        brp.x = q.x; brp.v = q.v; brp.a = q.a;
+        brp.dt = c->dt;
+        brp.mode = 0;
+    } else if (runs) {
         if (int rc = ensure_slabs(c, (size_t)ry.max_slabs * n * sizeof(float4))) return rc;
         run_params(&rp, reinterpret_cast<const float4*>(d_bodies), n, ry, static_cast<float4*>(c->slabs), c->eps2);
         q.slabs = static_cast<const float4*>(c->slabs);
@@ -1248,6 +1402,10 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
     // one step = one force launch + one integrate launch, both checked
     auto enqueue_step = [&](bool timed) -> int {
         int rc;
+        if (bal) {
+            if (int rb = launch_bal(c, bp, timed)) return rb;
+            return launch_bal_reduce(c, brp);   // the inbox sum and the integrate in one kernel
+        }
         if (runs) rc = launch_run(c, ry, rp);
         else if (sym) rc = timed ? launch_sym(c, y, sp) : launch_sym_untimed(c, y, sp);
         else rc = timed ? launch_force(c, s, p) : launch_force_untimed(c, s, p);
@@ -1261,8 +1419,9 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
     if (graphable && steps >= kGraphChunk) {
         // Launch-bound regime: replay a captured chain of kGraphChunk steps instead of 2*kGraphChunk
         // host launches. The kernels and their order are exactly those of the loop below.
-        const nbody_ctx::GraphKey key{d_bodies, q.a, q.v, c->slabs, n, runs ? ry.bpl : sym ? y.bpl : s.bpl, runs ? -1 : sym ? y.waves : s.tile,
-                                      runs ? ry.layout.L : sym ? y.nb : s.jsplit, c->kernel, kGraphChunk, c->dt, c->eps2, c->stream};
+        const nbody_ctx::GraphKey key{d_bodies, q.a, q.v, c->slabs, n, bal ? by.y.bpl : runs ? ry.bpl : sym ? y.bpl : s.bpl,
+                                      bal ? -2 : runs ? -1 : sym ? y.waves : s.tile, bal ? by.y.L : runs ? ry.layout.L : sym ? y.nb : s.jsplit,
+                                      c->kernel, kGraphChunk, c->dt, c->eps2, c->stream};
         if (!c->graph_exec || !(key == c->graph_key)) {
             if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
             if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }

@@ -568,8 +568,8 @@ __device__ __forceinline__ int sym_row_offset(int I, int nb) { return (int)(((lo
 
 // block = 64*W threads. rect == 0: grid = nb*(nb-1)/2 pair tasks followed by nb diagonal tasks;
 // rect == 1: grid = nbi*nbj pair tasks.
-template <class M, int W, int MINW = 1>
-__global__ void __launch_bounds__(64 * W, MINW) force_sym(const SymParamsT<typename M::V4, typename M::S> p)
+template <class M, int W>
+__device__ __forceinline__ void force_sym_body(const SymParamsT<typename M::V4, typename M::S>& p)
 {
     constexpr int BPL = M::BPL;
     constexpr int B = 64 * W * BPL;
@@ -669,6 +669,111 @@ __global__ void __launch_bounds__(64 * W, MINW) force_sym(const SymParamsT<typen
             }
         }
     }
+}
+
+template <class M, int W, int MINW = 1>
+__global__ void __launch_bounds__(64 * W, MINW) force_sym(const SymParamsT<typename M::V4, typename M::S> p)
+{
+    force_sym_body<M, W>(p);
+}
+
+// The SQUARE case alone (one range against itself: rect == 0, no wrap, i0 == j0): the same tasks, the same arithmetic and the same
+// slab layout as force_sym, without the run-time rectangle / wrap-around handling. Measured 2.7 % faster than the general kernel at
+// N = 262144 (tools/symbench.hip, profiles/r03_symbench_rows.txt: 10.98 vs 11.29 ms per launch on one box) — the instruction
+// schedule of the rotation pass that hipcc finds for the simpler control flow, not a different algorithm.
+template <class M, int W>
+__global__ void __launch_bounds__(64 * W, 1) force_sym_square(const SymParamsT<typename M::V4, typename M::S> p)
+{
+    constexpr int BPL = M::BPL;
+    constexpr int B = 64 * W * BPL;
+    constexpr int NCH = B / 64;
+    using V4 = typename M::V4;
+    __shared__ V4 sh[B];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = p.nbi;
+    const int task = p.task0 + (int)blockIdx.x;
+    const int npair = nb * (nb - 1) / 2;
+    const bool diag = task >= npair;
+    int I, J;
+    if (diag) {
+        I = J = task - npair;
+    } else {
+        const float q = 2.0f * nb - 1.0f;
+        I = (int)((q - __builtin_sqrtf(q * q - 8.0f * (float)task)) * 0.5f);
+        if (I < 0) I = 0;
+        if (I > nb - 2) I = nb - 2;
+        while (I < nb - 2 && sym_row_offset(I + 1, nb) <= task) ++I;
+        while (I > 0 && sym_row_offset(I, nb) > task) --I;
+        J = I + 1 + (task - sym_row_offset(I, nb));
+    }
+    const V4* const x = p.x + p.i0;
+    const int n = p.ni;
+    M t;
+    t.set_eps2(p.eps2);
+    const int ibase = I * B + w * (64 * BPL) + lane;
+#pragma unroll
+    for (int k = 0; k < BPL; ++k) {
+        const int i = ibase + k * 64;
+        t.set(k, i < n ? x[i] : zero4<V4>());
+    }
+    const int rot = ((lane + 16) & 63) << 2;
+    const int jbase = J * B + lane;
+    auto fetch = [&](int c) {
+        const int j = jbase + c * 64;
+        return j < n ? x[j] : zero4<V4>();
+    };
+    if (!diag) {
+#pragma unroll
+        for (int r = 0; r < BPL; ++r) sh[r * (64 * W) + tid] = zero4<V4>();
+        __syncthreads();
+    }
+    int c = w * BPL;
+    V4 nxt = fetch(c);
+    for (int q = 0; q < NCH; ++q) {
+        V4 bj = nxt;
+        const int cn = (c + 1 == NCH) ? 0 : c + 1;
+        if (q + 1 < NCH) nxt = fetch(cn);
+        if (diag) {
+            V4 aj = zero4<V4>();
+            for (int ph = 0; ph < 4; ++ph) {
+                sym_row_pass<false>(t, bj, aj);
+                bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot); bj.w = next_row(bj.w, rot);
+            }
+        } else {
+            V4 aj = sh[c * 64 + lane];
+            for (int ph = 0; ph < 4; ++ph) {
+                sym_row_pass<true>(t, bj, aj);
+                bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot); bj.w = next_row(bj.w, rot);
+                aj.x = next_row(aj.x, rot); aj.y = next_row(aj.y, rot); aj.z = next_row(aj.z, rot);
+            }
+            sh[c * 64 + lane] = aj;
+            __syncthreads();
+        }
+        c = cn;
+    }
+    if (!diag) {
+        V4* const out_j = p.slabs_j + (size_t)I * p.stride_j;
+        for (int e = tid; e < B; e += 64 * W) {
+            const int j = J * B + e;
+            if (j < n) { V4 a = sh[e]; a.w = 0; out_j[j] = a; }
+        }
+    }
+    V4* const out_i = p.slabs_i + (size_t)J * p.stride_i;
+#pragma unroll
+    for (int k = 0; k < BPL; ++k) {
+        const int i = ibase + k * 64;
+        if (i < n) out_i[i] = t.acc(k);
+    }
+}
+
+// The same kernel compiled for EXACTLY WPS waves per SIMD (amdgpu_waves_per_eu): the register allocator may then use the whole
+// budget of that occupancy (256 VGPRs at two waves) instead of stopping at its own estimate (196 for SymPacked<10>).
+template <class M, int W, int WPS>
+__global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
+force_sym_wps(const SymParamsT<typename M::V4, typename M::S> p)
+{
+    force_sym_body<M, W>(p);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -797,8 +902,13 @@ __global__ void __launch_bounds__(64) force_sym_run(const RunParams p)
 //     above the chunk's own block (record `piece` = which of the workers that share the unit wrote it; pieces that do not exist are
 //     never written and stay zero from the one-time clear of the workspace), then one record per worker that touched the chunk's
 //     own row (I-side sums). Every record has exactly one writer; nothing is atomic.
-//   * bal_reduce streams a chunk's records (no lookups: the count follows from two divisions), P waves taking every P-th record,
-//     adds them in record order and then over the waves — a fixed order, reproducible run to run — and integrates.
+//   * WV consecutive workers form one workgroup. They finish together (equal work), and those that end in the same row hold sums
+//     for the SAME I-block: they add them up through LDS (in worker order) and the first of them writes ONE record — the workgroup's
+//     tile becomes 64*bpl x WV*L pairs, near square, which is what keeps the partial-sum volume at N*sqrt(2*workgroups) instead of
+//     N*sqrt(2*waves) (N = 8192, 4 bodies per lane: 4.7 MB instead of 12.8 MB per step). Records of the other workers of such a run
+//     are never written and never read.
+//   * bal_reduce streams a chunk's records (no memory lookups: which records exist follows from a few integer divisions), P waves
+//     taking every P-th item, adds them in a fixed order and then over the waves — reproducible run to run — and integrates.
 
 struct BalLayout {
     int bpl;       // stationary bodies per lane; an I-block is 64*bpl bodies
@@ -806,6 +916,7 @@ struct BalLayout {
     int ncht;      // 64-body chunks in the system
     int L;         // rotation steps per worker
     int nworkers;
+    int wv;        // workers (waves) per workgroup: consecutive workers that end in the same row combine their I-side sums
     int pmax;      // records a unit's J-side sums can be spread over (workers sharing one unit)
     int smax;      // records per inbox
     int nsteps;    // 64 * units (< 2^31: checked on the host)
@@ -834,13 +945,32 @@ __host__ __device__ inline void bal_row_workers(int K, const BalLayout& y, unsig
     *gl = ((row1 << 6) - 1u) / (unsigned)y.L;
 }
 
-// Host side: the layout for n bodies with `bpl` stationary bodies per lane and about `workers_target` workers (resident waves).
-// false when the decomposition does not apply (fewer than two chunks, step count beyond 2^31).
-inline bool bal_plan(int n, int bpl, int workers_target, BalLayout* out)
+// last row worker g has steps in, and whether that worker exists at all
+__host__ __device__ inline int bal_last_row(int g, const BalLayout& y)
 {
-    if (n < 128 || bpl < 1 || workers_target < 1) return false;
+    const long e = (long)(g + 1) * y.L;
+    const int last = (int)((e < y.nsteps ? e : (long)y.nsteps) - 1);
+    return bal_row_of_unit(last >> 6, y);
+}
+
+// Does worker g (gf <= g <= gl, the workers of row K) write its row-K sums itself? Not when it is a follower of a combined run:
+// a worker that ENDS in row K, is not the first of its workgroup and whose predecessor also ends in row K (true for every
+// predecessor >= gf: its range ends where g's begins, inside row K).
+__host__ __device__ inline bool bal_writes_iside(unsigned g, unsigned gf, unsigned gl, bool gl_ends_in_row, const BalLayout& y)
+{
+    if (g == gf || (g % (unsigned)y.wv) == 0) return true;
+    if (g < gl) return false;          // gf < g < gl: ends in row K, predecessor too
+    return !gl_ends_in_row;            // g == gl: a follower only when its last row is K
+}
+
+// Host side: the layout for n bodies with `bpl` stationary bodies per lane and about `workers_target` workers (resident waves) in
+// workgroups of `wv`. false when the decomposition does not apply (fewer than two chunks, step count beyond 2^31).
+inline bool bal_plan(int n, int bpl, int workers_target, int wv, BalLayout* out)
+{
+    if (n < 128 || bpl < 1 || workers_target < 1 || wv < 1) return false;
     BalLayout y{};
     y.bpl = bpl;
+    y.wv = wv;
     y.ncht = (n + 63) / 64;
     y.nbi = (n + 64 * bpl - 1) / (64 * bpl);
     const long units = (long)y.nbi * y.ncht - (long)bpl * ((long)y.nbi * (y.nbi - 1) / 2);
@@ -893,17 +1023,20 @@ __device__ __forceinline__ void sym_row_range(M& t, const typename M::V4& bj, ty
     sym_step_if<15, SYM>(t, bj, aj, ta, tb);
 }
 
-template <class M>
-__global__ void __launch_bounds__(64) force_sym_bal(const BalParams p)
+template <class M, int WV>
+__global__ void __launch_bounds__(64 * WV) force_sym_bal(const BalParams p)
 {
     constexpr int BPL = M::BPL;
-    const int lane = threadIdx.x;
-    const int g = blockIdx.x;
+    __shared__ float4 sh[WV][64 * BPL];
+    __shared__ int sh_row[WV];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = blockIdx.x * WV + w;
     const BalLayout& y = p.y;
-    int s = g * y.L;
+    int s = g < y.nworkers ? g * y.L : y.nsteps;
     const int s1 = (s + y.L < y.nsteps) ? s + y.L : y.nsteps;
-    if (s >= s1) return;
-    int I = bal_row_of_unit(s >> 6, y);
+    int I = s < s1 ? bal_row_of_unit(s >> 6, y) : 0;
+    int my_last_row = -1;
     const int rot = ((lane + 16) & 63) << 2;
     // chunk c as seen in row phase ph: lane l holds body (l + 16*ph) & 63 of the chunk
     auto fetch = [&](int c, int ph) {
@@ -956,15 +1089,41 @@ __global__ void __launch_bounds__(64) force_sym_bal(const BalParams p)
             }
             s = uend;
         }
-        // I-side sums: one record in the inbox of each of the block's chunks, after the J-side runs of the rows above
-        unsigned gf, gl;
-        bal_row_workers(I, y, &gf, &gl);
-        const int rec = I * y.pmax + (g - (int)gf);
+        if (s < s1) {
+            // the worker goes on into the next row: these I-side sums are complete, one record in the inbox of each of the block's
+            // chunks (after the J-side runs of the rows above)
+            unsigned gf, gl;
+            bal_row_workers(I, y, &gf, &gl);
+            const int rec = I * y.pmax + (g - (int)gf);
 #pragma unroll
-        for (int k = 0; k < BPL; ++k) {
-            const int c = I * BPL + k;
-            if (c < y.ncht) p.inbox[((size_t)c * y.smax + rec) * 64 + lane] = t.acc(k);
+            for (int k = 0; k < BPL; ++k) {
+                const int c = I * BPL + k;
+                if (c < y.ncht) p.inbox[((size_t)c * y.smax + rec) * 64 + lane] = t.acc(k);
+            }
+        } else {
+            my_last_row = I;   // the last row of this worker: its sums meet those of its workgroup neighbours in LDS
+#pragma unroll
+            for (int k = 0; k < BPL; ++k) sh[w][k * 64 + lane] = t.acc(k);
         }
+    }
+    if (lane == 0) sh_row[w] = my_last_row;
+    __syncthreads();
+    // a run of consecutive workers that end in the same row: the first adds the run up (worker order) and writes one record
+    if (my_last_row < 0 || (w > 0 && sh_row[w - 1] == my_last_row)) return;
+    int run = 1;
+    while (w + run < WV && sh_row[w + run] == my_last_row) ++run;
+    unsigned gf, gl;
+    bal_row_workers(my_last_row, y, &gf, &gl);
+    const int rec = my_last_row * y.pmax + (g - (int)gf);
+#pragma unroll
+    for (int k = 0; k < BPL; ++k) {
+        float4 a = sh[w][k * 64 + lane];
+        for (int q = 1; q < run; ++q) {
+            const float4 b = sh[w + q][k * 64 + lane];
+            a.x += b.x; a.y += b.y; a.z += b.z;
+        }
+        const int c = my_last_row * BPL + k;
+        if (c < y.ncht) p.inbox[((size_t)c * y.smax + rec) * 64 + lane] = a;
     }
 }
 
@@ -994,22 +1153,60 @@ __global__ void __launch_bounds__(64 * P) bal_reduce(const BalReduceParams p)
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = blockIdx.x;
     const int K = c / y.bpl;
-    unsigned gf, gl;
-    bal_row_workers(K, y, &gf, &gl);
-    const int nrec = K * y.pmax + (int)(gl - gf + 1);
+    const unsigned L = (unsigned)y.L;
     const float4* const box = p.inbox + (size_t)c * y.smax * 64 + lane;
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    int r = w;
-    for (; r + 7 * P < nrec; r += 8 * P) {   // eight independent loads in flight, added in record order
-        float4 q[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) q[e] = box[(size_t)(r + e * P) * 64];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { acc.x += q[e].x; acc.y += q[e].y; acc.z += q[e].z; }
+    auto add = [&](const float4 q) { acc.x += q.x; acc.y += q.y; acc.z += q.z; };
+    // the wave that will integrate asks for its bodies' state now: the loads fly while the records are summed
+    const int i = c * 64 + lane;
+    float4 v0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), x0 = v0;
+    if (w == 0 && i < p.n) {
+        if (p.mode == 0) { v0 = p.v[i]; x0 = p.x[i]; }
+        else if (p.accumulate) v0 = p.a[i];
     }
-    for (; r < nrec; r += P) {
-        const float4 q = box[(size_t)r * 64];
-        acc.x += q.x; acc.y += q.y; acc.z += q.z;
+    // J side: rows above the chunk's own block; unit (I, c) was shared by workers S/L .. (S+63)/L, one record each
+    for (int I = w; I < K; I += 2 * P) {   // two rows at a time: up to 2*pmax loads in flight
+        const int I2 = I + P;
+        const unsigned Sa = ((unsigned)(bal_row_prefix(I, y) + (c - I * y.bpl))) << 6;
+        const int npa = (int)((Sa + 63u) / L - Sa / L) + 1;
+        int npb = 0;
+        if (I2 < K) {
+            const unsigned Sb = ((unsigned)(bal_row_prefix(I2, y) + (c - I2 * y.bpl))) << 6;
+            npb = (int)((Sb + 63u) / L - Sb / L) + 1;
+        }
+        float4 qa[5], qb[5];   // pmax <= 5 (L >= 16)
+#pragma unroll
+        for (int e = 0; e < 5; ++e) {
+            qa[e] = e < npa ? box[(size_t)(I * y.pmax + e) * 64] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            qb[e] = e < npb ? box[(size_t)(I2 * y.pmax + e) * 64] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int e = 0; e < 5; ++e) if (e < npa) add(qa[e]);
+#pragma unroll
+        for (int e = 0; e < 5; ++e) if (e < npb) add(qb[e]);
+    }
+    // I side: the workers of row K that wrote a record (first of the row, first of each workgroup, a last worker that goes on)
+    {
+        unsigned gf, gl;
+        bal_row_workers(K, y, &gf, &gl);
+        const bool gl_ends = bal_last_row((int)gl, y) == K;
+        const float4* const ibox = box + (size_t)K * y.pmax * 64;
+        const unsigned wv = (unsigned)y.wv;
+        // item 0 = gf; items 1 .. m = the multiples of wv in (gf, gl]; one more when gl itself writes and is not a multiple
+        const unsigned first_mult = (gf / wv + 1u) * wv;
+        const int m = first_mult <= gl ? (int)((gl - first_mult) / wv) + 1 : 0;
+        const bool extra = gl > gf && (gl % wv) != 0 && bal_writes_iside(gl, gf, gl, gl_ends, y);
+        const int items = 1 + m + (extra ? 1 : 0);
+        auto worker_of = [&](int e) -> unsigned { return e == 0 ? gf : (e <= m ? first_mult + (unsigned)(e - 1) * wv : gl); };
+        int e = w;
+        for (; e + 3 * P < items; e += 4 * P) {
+            float4 q[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = ibox[(size_t)(worker_of(e + k * P) - gf) * 64];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) add(q[k]);
+        }
+        for (; e < items; e += P) add(ibox[(size_t)(worker_of(e) - gf) * 64]);
     }
     sh[w][lane] = acc;
     __syncthreads();
@@ -1021,19 +1218,15 @@ __global__ void __launch_bounds__(64 * P) bal_reduce(const BalReduceParams p)
         a.x += b.x; a.y += b.y; a.z += b.z;
     }
     a.w = 0.0f;
-    const int i = c * 64 + lane;
     if (i >= p.n) return;
     if (p.mode == 1) {
-        if (p.accumulate) {
-            const float4 o = p.a[i];
-            a.x += o.x; a.y += o.y; a.z += o.z;
-        }
+        if (p.accumulate) { a.x += v0.x; a.y += v0.y; a.z += v0.z; }
         p.a[i] = a;
         return;
     }
     p.a[i] = a;
-    float4 v = p.v[i];
-    float4 x = p.x[i];
+    float4 v = v0;
+    float4 x = x0;
     const float hdt = 0.5f * p.dt;
     v.x += hdt * a.x; v.y += hdt * a.y; v.z += hdt * a.z;
     x.x += p.dt * v.x; x.y += p.dt * v.y; x.z += p.dt * v.z;

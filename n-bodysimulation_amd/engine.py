@@ -93,7 +93,8 @@ class Context:
         check(self._lib.nbody_ctx_set_symmetric_shape(self._h, waves, bodies_per_lane))
 
     def set_symmetric_runs(self, mode: int) -> None:
-        """Run-based decomposition of the symmetric kernel: -1 where the cost estimate prefers it, 0 never, 1 always."""
+        """Run-based decompositions of the symmetric kernel: -1 where measurements prefer them, 0 never, 1 unit runs always,
+        2 balanced (step-granular) runs always."""
         check(self._lib.nbody_ctx_set_symmetric_runs(self._h, mode))
 
     def set_workspace_limit(self, nbytes: int = 0, fail_above: bool = False) -> None:
@@ -119,16 +120,13 @@ class Context:
 
     def step_info(self, n: int) -> dict:
         """What a whole step of n bodies launches (symmetric or one-sided kernel, slabs, pair evaluations)."""
-        sym, blk, slabs, wgs, ev = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_double()
-        check(self._lib.nbody_ctx_step_info(self._h, n, C.byref(sym), C.byref(blk), C.byref(slabs), C.byref(wgs), C.byref(ev)))
-        return {"symmetric": bool(sym.value), "runs": sym.value == 2, "block_bodies": blk.value, "slabs": slabs.value,
-                "workgroups": wgs.value, "evaluated_pairs": ev.value}
+        return self._info(self._lib.nbody_ctx_step_info, n)
 
     def _info(self, fn, *args) -> dict:
         sym, blk, slabs, wgs, ev = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_double()
         check(fn(self._h, *args, C.byref(sym), C.byref(blk), C.byref(slabs), C.byref(wgs), C.byref(ev)))
-        return {"symmetric": bool(sym.value), "runs": sym.value == 2, "block_bodies": blk.value, "slabs": slabs.value,
-                "workgroups": wgs.value, "evaluated_pairs": ev.value}
+        return {"symmetric": bool(sym.value), "runs": sym.value == 2, "balanced": sym.value == 3, "block_bodies": blk.value,
+                "slabs": slabs.value, "workgroups": wgs.value, "evaluated_pairs": ev.value}
 
     def step_info_f64(self, n: int) -> dict:
         """What nbody_step_f64 launches for n bodies."""

@@ -442,7 +442,8 @@ def test_reference_shipped_size_fast_vs_literal_reference(nb, oracle, kernel):
     x0 = _ref_n8192_start(nb)
     k = {"fast": nb.KERNEL_FAST, "onesided": nb.KERNEL_ONESIDED, "symmetric": nb.KERNEL_SYMMETRIC}[kernel]
     sim = nb.engine.Simulation(x0, dt=0.1, eps2=0.002, kernel=k)
-    assert sim.ctx.step_info(8192)["symmetric"] == (kernel == "symmetric")
+    info = sim.ctx.step_info(8192)     # FAST at this size: the balanced-run symmetric variant; SYMMETRIC: block pairs; ONESIDED: one-sided
+    assert info["symmetric"] == (kernel != "onesided") and info["balanced"] == (kernel == "fast")
     xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
     oracle.step_jacobi(xo, ao, vo, dt=0.1, eps2=0.002, steps=1)
     sim.run(1)
@@ -976,3 +977,100 @@ def test_fp64_only_shape_request_is_auto_for_fp32(nb, oracle):
     ctx.sync()
     want = oracle.accel_range(x0, 0, 2000, 2500, 5500, eps2=0.002, f64acc=True)
     assert np.abs(ai.cpu().numpy() - want)[:, :3].max() / np.abs(want[:, :3]).max() <= 1e-5
+
+
+# ---- balanced runs: the symmetric kernel cut at rotation-step granularity (small and mid N) -------------------------------
+
+@pytest.mark.parametrize("n,bpl,init", [(128, 2, 0), (777, 2, 1), (1000, 4, 0), (3001, 4, 1), (4099, 8, 0), (6144, 10, 1), (8192, 0, 0),
+                                        (9000, 8, 1), (12345, 0, 1), (20000, 10, 0)])
+def test_balanced_runs_vs_oracle(nb, oracle, n, bpl, init):
+    """nbody_ctx_set_symmetric_runs(2): every worker the same number of rotation steps, units split between workers anywhere,
+    per-chunk inboxes, one reduce-and-integrate kernel. Ragged sizes (padding bodies), every bodies-per-lane shape, sizes where a
+    worker has fewer steps than a unit (units shared by 3+ workers): accelerations against the fp64-accumulated CPU sums,
+    momentum balance, w = 0, bitwise run-to-run reproducibility, and positions after the integrate against the Jacobi oracle."""
+    x0 = nb.engine.seeded_bodies(n, init, 11)
+    dt = 0.1 if init == 0 else 0.01
+    sim = nb.engine.Simulation(x0, dt=dt, eps2=0.002, kernel=nb.KERNEL_SYMMETRIC)
+    sim.ctx.set_symmetric_shape(0, bpl)
+    sim.ctx.set_symmetric_runs(2)
+    sim.ctx.reserve(n)
+    info = sim.ctx.step_info(n)
+    assert info["balanced"] and info["symmetric"] and not info["runs"]
+    assert info["block_bodies"] == 64 * (bpl or info["block_bodies"] // 64)
+    bi = info["block_bodies"]                       # each unordered pair once, plus the diagonal blocks both ways and the padding
+    assert 0.5 * n * n <= info["evaluated_pairs"] <= 0.5 * (n + bi) ** 2 + (n + bi) * bi
+    sim.run(1)
+    x, v, a = sim.state()
+    truth = oracle.accel_range(x0, 0, n, eps2=0.002, f64acc=True)
+    amax = np.abs(truth[:, :3]).max()
+    assert np.abs(a - truth)[:, :3].max() / amax <= 1e-5
+    assert np.all(a[:, 3] == 0) and np.all(v[:, 3] == 0) and np.array_equal(x[:, 3], x0[:, 3])
+    m = x0[:, 3:4].astype(np.float64)
+    assert np.abs((m * a[:, :3]).sum(0)).max() / (m * np.abs(a[:, :3])).sum() < 1e-6
+    xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
+    oracle.step_jacobi(xo, ao, vo, dt=dt, eps2=0.002)
+    assert np.abs(x - xo)[:, :3].max() / (1e5 if init == 0 else 1.0) <= 1e-6
+    again = nb.engine.Simulation(x0, dt=dt, eps2=0.002, kernel=nb.KERNEL_SYMMETRIC)
+    again.ctx.set_symmetric_shape(0, bpl)
+    again.ctx.set_symmetric_runs(2)
+    again.run(1)
+    x2, v2, a2 = again.state()
+    assert np.array_equal(a, a2) and np.array_equal(x, x2) and np.array_equal(v, v2)
+
+
+def test_balanced_runs_are_what_fast_picks_at_the_reference_size(nb, oracle):
+    """FAST at the reference's shipped N_BODIES = 8192 (constants.h:13), at 16384 and at 32768 is the balanced-run variant; 4096 stays
+    one-sided, 65536 goes to unit runs. Ten steps at N = 8192 from the reference's kind of initial conditions against the Jacobi
+    oracle, and the square block of nbody_accel_range (accumulate on and off) through the same kernels."""
+    ctx = nb.engine.Context()
+    assert not ctx.step_info(4096)["symmetric"]
+    for n in (8192, 16384, 32768):
+        assert ctx.step_info(n)["balanced"], n
+    assert ctx.step_info(65536)["runs"] and ctx.step_info(262144)["symmetric"] and not ctx.step_info(262144)["balanced"]
+    n = 8192
+    x0 = nb.engine.seeded_bodies(n, 0, 3)
+    sim = nb.engine.Simulation(x0, dt=0.1, eps2=0.002)
+    sim.run(10)
+    x, v, a = sim.state()
+    xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
+    oracle.step_jacobi(xo, ao, vo, dt=0.1, eps2=0.002, steps=10)
+    assert np.abs(x - xo)[:, :3].max() / 1e5 <= 1e-5             # ten steps: the bar of test_reference_shipped_size_*
+    assert nb.engine.verify_still_bodies(x, xo) == 0
+    xd = torch.from_numpy(x0).cuda()
+    out = torch.full((n, 4), 7.0, device="cuda")
+    ctx2 = nb.engine.Context(eps2=0.002)
+    ctx2.accel_range(xd, out, 0, n, 0, n)
+    ctx2.sync()
+    a1 = out.cpu().numpy()
+    truth = oracle.accel_range(x0, 0, n, eps2=0.002, f64acc=True)
+    assert np.abs(a1 - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 1e-5
+    ctx2.accel_range(xd, out, 0, n, 0, n, accumulate=True)
+    ctx2.sync()
+    assert np.abs(out.cpu().numpy() - 2 * a1)[:, :3].max() / np.abs(a1[:, :3]).max() <= 1e-6
+
+
+def test_balanced_runs_workspace_is_recleared_after_other_users(nb, oracle):
+    """The inboxes rely on never-written records reading as zero. Anything else that uses the context's workspace in between
+    (another size, the one-sided kernel on a rectangle, block pairs) must trigger a fresh clear: same bits afterwards."""
+    n = 10000
+    x0 = nb.engine.seeded_bodies(n, 1, 5)
+    x = torch.from_numpy(x0).cuda()
+    ctx = nb.engine.Context(dt=0.01, eps2=0.002)
+    assert ctx.step_info(n)["balanced"]
+    a1 = torch.zeros((n, 4), device="cuda")
+    ctx.accel_range(x, a1, 0, n, 0, n)
+    ctx.sync()
+    junk = torch.zeros((3000, 4), device="cuda")
+    ctx.accel_range(x, junk, 0, 3000, 2000, 9000)              # a rectangle: one-sided kernel, writes slabs over the inboxes
+    big = torch.from_numpy(nb.engine.seeded_bodies(30000, 1, 6)).cuda()
+    abig = torch.zeros((30000, 4), device="cuda")
+    ctx.accel_range(big, abig, 0, 30000, 0, 30000)              # another balanced layout (and a larger workspace)
+    ctx.set_symmetric_runs(0)
+    ctx.accel_range(big, abig, 0, 30000, 0, 30000)              # block pairs over the same workspace
+    ctx.set_symmetric_runs(-1)
+    a2 = torch.zeros((n, 4), device="cuda")
+    ctx.accel_range(x, a2, 0, n, 0, n)
+    ctx.sync()
+    assert torch.equal(a1, a2)
+    truth = oracle.accel_range(x0, 0, 1024, 0, n, eps2=0.002, f64acc=True)
+    assert np.abs(a2.cpu().numpy()[:1024] - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 1e-5

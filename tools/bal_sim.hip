@@ -23,19 +23,25 @@ static double wgt(int i, int j)   // antisymmetric pseudo-random weight, exactly
     return i < j ? v : -v;
 }
 
-static bool run_case(int n, int bpl, int workers, int P)
+static bool run_case(int n, int bpl, int workers, int P, int wv)
 {
     nbk::BalLayout y{};
-    if (!nbk::bal_plan(n, bpl, workers, &y)) { printf("n=%d bpl=%d: no plan\n", n, bpl); return true; }
+    if (!nbk::bal_plan(n, bpl, workers, wv, &y)) { printf("n=%d bpl=%d: no plan\n", n, bpl); return true; }
     const int BI = 64 * bpl;
     std::vector<double> inbox((size_t)y.ncht * y.smax * 64, 0.0);     // cleared once, as the library does
     std::vector<char> written((size_t)y.ncht * y.smax, 0);
     long steps_done = 0;
-    for (int g = 0; g < y.nworkers; ++g) {   // force_sym_bal, one worker
-        int s = g * y.L;
+    std::vector<std::vector<double>> lds(wv);     // the workgroup's LDS: last-row sums of each of its workers
+    std::vector<int> lds_row(wv, -1);
+    const int ngroups = (y.nworkers + wv - 1) / wv;
+    for (int grp = 0; grp < ngroups; ++grp) {
+    for (int w = 0; w < wv; ++w) {   // force_sym_bal, one worker
+        const int g = grp * wv + w;
+        lds_row[w] = -1;
+        int s = g < y.nworkers ? g * y.L : y.nsteps;
         const int s1 = (s + y.L < y.nsteps) ? s + y.L : y.nsteps;
-        int I = nbk::bal_row_of_unit(s >> 6, y);
-        if (!(nbk::bal_row_prefix(I, y) <= (s >> 6) && (s >> 6) < nbk::bal_row_prefix(I + 1, y))) { printf("bad row of unit\n"); return false; }
+        int I = s < s1 ? nbk::bal_row_of_unit(s >> 6, y) : 0;
+        if (s < s1 && !(nbk::bal_row_prefix(I, y) <= (s >> 6) && (s >> 6) < nbk::bal_row_prefix(I + 1, y))) { printf("bad row of unit\n"); return false; }
         for (; s < s1; ++I) {
             const int row0 = nbk::bal_row_prefix(I, y), row1 = nbk::bal_row_prefix(I + 1, y);
             const int seg1 = (row1 << 6) < s1 ? (row1 << 6) : s1;
@@ -78,15 +84,42 @@ static bool run_case(int n, int bpl, int workers, int P)
             unsigned gf, gl;
             nbk::bal_row_workers(I, y, &gf, &gl);
             if ((unsigned)g < gf || (unsigned)g > gl) { printf("worker outside its row's range\n"); return false; }
-            const int recI = I * y.pmax + (g - (int)gf);
-            if (recI >= y.smax) { printf("smax overflow\n"); return false; }
-            for (int k = 0; k < bpl; ++k) {
-                const int c = I * bpl + k;
-                if (c >= y.ncht) continue;
-                if (written[(size_t)c * y.smax + recI]++) { printf("I record written twice\n"); return false; }
-                for (int lane = 0; lane < 64; ++lane) inbox[((size_t)c * y.smax + recI) * 64 + lane] = acc[(size_t)k * 64 + lane];
+            if (s < s1) {   // goes on into the next row: writes this row's record itself
+                const int recI = I * y.pmax + (g - (int)gf);
+                if (recI >= y.smax) { printf("smax overflow\n"); return false; }
+                for (int k = 0; k < bpl; ++k) {
+                    const int c = I * bpl + k;
+                    if (c >= y.ncht) continue;
+                    if (written[(size_t)c * y.smax + recI]++) { printf("I record written twice\n"); return false; }
+                    for (int lane = 0; lane < 64; ++lane) inbox[((size_t)c * y.smax + recI) * 64 + lane] = acc[(size_t)k * 64 + lane];
+                }
+            } else {
+                lds[w] = acc;
+                lds_row[w] = I;
+                if (nbk::bal_last_row(g, y) != I) { printf("bal_last_row disagrees\n"); return false; }
             }
         }
+    }
+    for (int w = 0; w < wv; ++w) {   // after the barrier: the first worker of every run of equal last rows writes the run's sum
+        const int g = grp * wv + w, row = lds_row[w];
+        if (row < 0 || (w > 0 && lds_row[w - 1] == row)) continue;
+        int run = 1;
+        while (w + run < wv && lds_row[w + run] == row) ++run;
+        unsigned gf, gl;
+        nbk::bal_row_workers(row, y, &gf, &gl);
+        const int recI = row * y.pmax + (g - (int)gf);
+        if (recI >= y.smax) { printf("smax overflow\n"); return false; }
+        for (int k = 0; k < bpl; ++k) {
+            const int c = row * bpl + k;
+            if (c >= y.ncht) continue;
+            if (written[(size_t)c * y.smax + recI]++) { printf("I record written twice\n"); return false; }
+            for (int lane = 0; lane < 64; ++lane) {
+                double a = 0.0;
+                for (int q = 0; q < run; ++q) a += lds[w + q][(size_t)k * 64 + lane];
+                inbox[((size_t)c * y.smax + recI) * 64 + lane] = a;
+            }
+        }
+    }
     }
     if (steps_done != y.nsteps) { printf("steps %ld != %d\n", steps_done, y.nsteps); return false; }
     // bal_reduce
@@ -94,17 +127,34 @@ static bool run_case(int n, int bpl, int workers, int P)
     long terms = 0;
     for (int c = 0; c < y.ncht; ++c) {
         const int K = c / bpl;
+        const unsigned L = (unsigned)y.L;
+        std::vector<int> recs;   // the records the reducer reads, in its order (P does not change the set)
+        for (int I = 0; I < K; ++I) {
+            const unsigned S = ((unsigned)(nbk::bal_row_prefix(I, y) + (c - I * bpl))) << 6;
+            const int np = (int)((S + 63u) / L - S / L) + 1;
+            if (np > y.pmax) { printf("np > pmax\n"); return false; }
+            for (int e = 0; e < np; ++e) recs.push_back(I * y.pmax + e);
+        }
         unsigned gf, gl;
         nbk::bal_row_workers(K, y, &gf, &gl);
-        const int nrec = K * y.pmax + (int)(gl - gf + 1);
-        for (int r = K * y.pmax; r < nrec; ++r)
-            if (!written[(size_t)c * y.smax + r]) { printf("I-side record %d of chunk %d never written\n", r, c); return false; }
+        const bool gl_ends = nbk::bal_last_row((int)gl, y) == K;
+        const unsigned uw = (unsigned)wv, first_mult = (gf / uw + 1u) * uw;
+        const int m = first_mult <= gl ? (int)((gl - first_mult) / uw) + 1 : 0;
+        const bool extra = gl > gf && (gl % uw) != 0 && nbk::bal_writes_iside(gl, gf, gl, gl_ends, y);
+        for (int e = 0; e < 1 + m + (extra ? 1 : 0); ++e) {
+            const unsigned g = e == 0 ? gf : (e <= m ? first_mult + (unsigned)(e - 1) * uw : gl);
+            recs.push_back(K * y.pmax + (int)(g - gf));
+        }
+        size_t nwritten = 0;
+        for (int r = 0; r < y.smax; ++r) nwritten += written[(size_t)c * y.smax + r] ? 1 : 0;
+        if (nwritten != recs.size()) { printf("chunk %d: %zu records written, %zu read\n", c, nwritten, recs.size()); return false; }
+        for (int r : recs)
+            if (!written[(size_t)c * y.smax + r]) { printf("record %d of chunk %d read but never written\n", r, c); return false; }
         for (int lane = 0; lane < 64; ++lane) {
             const int i = c * 64 + lane;
             if (i >= n) continue;
             double sum = 0.0;
-            for (int w = 0; w < P; ++w)
-                for (int r = w; r < nrec; r += P) { sum += inbox[((size_t)c * y.smax + r) * 64 + lane]; ++terms; }
+            for (int r : recs) { sum += inbox[((size_t)c * y.smax + r) * 64 + lane]; ++terms; }
             double want = 0.0;
             for (int j = 0; j < n; ++j) want += wgt(i, j);
             const double e = std::fabs(sum - want);
@@ -112,8 +162,9 @@ static bool run_case(int n, int bpl, int workers, int P)
             if (e > worst) worst = e;
         }
     }
-    printf("n=%5d bpl=%2d workers=%5d (L=%4d, %5d used, pmax %d smax %3d) P=%d: ok, %.1f records/body, worst %.2g\n", n, bpl, workers, y.L,
-           y.nworkers, y.pmax, y.smax, P, (double)terms / n, worst);
+    (void)P;
+    printf("n=%5d bpl=%2d workers=%5d wv=%d (L=%4d, %5d used, pmax %d smax %3d): ok, %.1f records/body, worst %.2g\n", n, bpl, workers, wv, y.L,
+           y.nworkers, y.pmax, y.smax, (double)terms / n, worst);
     return true;
 }
 
@@ -123,7 +174,8 @@ int main()
     for (int n : {128, 129, 200, 777, 1000, 1024, 2050, 3001})
         for (int bpl : {2, 4, 8, 10})
             for (int workers : {1, 7, 64, 500, 2048, 100000})
-                ok = ok && run_case(n, bpl, workers, n % 2 ? 4 : 8);
+                for (int wv : {1, 4, 8})
+                    ok = ok && run_case(n, bpl, workers, 4, wv);
     printf(ok ? "ALL OK\n" : "FAILED\n");
     return ok ? 0 : 1;
 }

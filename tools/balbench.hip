@@ -60,8 +60,17 @@ static double us_per_call(const std::function<void()>& f, int steps, int reps = 
     return best;
 }
 
+template <class M, int WV>
+static void launch_bal_wv(const nbk::BalParams& p) { nbk::force_sym_bal<M, WV><<<(p.y.nworkers + WV - 1) / WV, 64 * WV>>>(p); }
 template <class M>
-static void launch_bal(const nbk::BalParams& p) { nbk::force_sym_bal<M><<<p.y.nworkers, 64>>>(p); }
+static void launch_bal(const nbk::BalParams& p)
+{
+    switch (p.y.wv) {
+        case 1: launch_bal_wv<M, 1>(p); break;
+        case 4: launch_bal_wv<M, 4>(p); break;
+        default: launch_bal_wv<M, 8>(p); break;
+    }
+}
 
 static void launch_reduce(const nbk::BalReduceParams& r, int P)
 {
@@ -157,10 +166,11 @@ int main(int argc, char** argv)
     for (int i = 0; i < n; ++i) scale = std::max({scale, (double)std::fabs(a_ref[i].x), (double)std::fabs(a_ref[i].y), (double)std::fabs(a_ref[i].z)});
 
     for (int bpl : {2, 4, 8, 10}) {
-        for (int wps : {2, 3, 4, 6}) {
-            if ((bpl == 10 && wps > 2) || (bpl == 8 && wps > 3)) continue;
+        for (int wps : {2, 3, 4}) {
+          for (int wv : {1, 4, 8}) {
+            if ((bpl == 10 && wps > 2) || (bpl == 8 && wps > 2) || (bpl == 2 && wps < 4) || (wps == 3 && wv == 1)) continue;
             nbk::BalLayout y{};
-            if (!nbk::bal_plan(n, bpl, simds * wps, &y)) continue;
+            if (!nbk::bal_plan(n, bpl, simds * wps, wv, &y)) continue;
             float4* inbox;
             const size_t ib = (size_t)y.ncht * y.smax * 64 * 16;
             CK(hipMalloc(&inbox, ib));
@@ -192,12 +202,12 @@ int main(int argc, char** argv)
                 if (!(e <= 1e30)) ++bad; else dmax = std::max(dmax, e);
             }
             const double t_f = us_per_call(force, steps);
-            printf("bal bpl %2d wps %d: workers %5d L %5d pmax %d smax %3d inbox %.1f MB | force %.2f us |", bpl, wps, y.nworkers, y.L, y.pmax,
+            printf("bal bpl %2d wps %d wv %d: workers %5d L %5d pmax %d smax %3d inbox %.1f MB | force %.2f us |", bpl, wps, wv, y.nworkers, y.L, y.pmax,
                    y.smax, ib / 1e6, t_f);
             rp.mode = 0;   // integrate (dt = 0)
             double best = 1e30;
             int bestP = 0;
-            for (int P : {2, 4, 8, 16}) {
+            for (int P : {4, 8, 16}) {
                 auto step = [&] { force(); launch_reduce(rp, P); };
                 const double t = us_per_call(step, steps);
                 printf(" P%d %.2f", P, t);
@@ -207,6 +217,7 @@ int main(int argc, char** argv)
                    pairs / best * 1e6, 20 * pairs / best * 1e6 / 157.3e12 * 100, dmax / scale, bad, err_vs_truth(a_bal));
             fflush(stdout);
             CK(hipFree(inbox));
+          }
         }
     }
     return 0;

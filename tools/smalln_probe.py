@@ -48,6 +48,14 @@ for n in sizes:
         sim.ctx.reserve(n)
         info = sim.ctx.step_info(n)
         row[f"runs_bpl{b}"] = dict(timed(sim), slabs=info["slabs"], workgroups=info["workgroups"])
+    for b in (4, 8, 10):
+        sim = nbody_amd.engine.Simulation(x0, dt=0.01, eps2=0.002, kernel=nbody_amd.KERNEL_SYMMETRIC)
+        sim.ctx.set_symmetric_shape(0, b)
+        sim.ctx.set_symmetric_runs(2)
+        sim.ctx.reserve(n)
+        info = sim.ctx.step_info(n)
+        if info["balanced"]:
+            row[f"balanced_bpl{b}"] = dict(timed(sim), records=info["slabs"], workgroups=info["workgroups"])
     sim = nbody_amd.engine.Simulation(x0, dt=0.01, eps2=0.002, kernel=nbody_amd.KERNEL_FAST)
     row["fast_auto"] = dict(timed(sim), info=sim.ctx.step_info(n))
     print(json.dumps(row), flush=True)

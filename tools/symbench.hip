@@ -296,11 +296,14 @@ int main(int argc, char** argv)
 
     std::vector<SymVariant> vars;
     vars.push_back(sym_variant<nbk::SymPacked<10>, 4>("sym packed bpl10 w4 (B=2560)"));
-    vars.push_back(sym_variant<nbk::SymPacked<10>, 4, 3>("sym packed bpl10 w4 minw3 (B=2560)"));
-    vars.push_back(sym_variant<nbk::SymPacked<10>, 3>("sym packed bpl10 w3 (B=1920)"));
-    vars.push_back(sym_variant<nbk::SymPacked<10>, 5>("sym packed bpl10 w5 (B=3200)"));
-    vars.push_back(sym_variant<nbk::SymPacked<10>, 8>("sym packed bpl10 w8 (B=5120)"));
+    vars.push_back({"sym bpl10 w4 SQUARE-only kernel", 2560, [](const nbk::SymParams& p, int grid) { nbk::force_sym_square<nbk::SymPacked<10>, 4><<<grid, 256>>>(p); }});
+    vars.push_back({"sym bpl10 w4 waves_per_eu(2,2)", 2560, [](const nbk::SymParams& p, int grid) { nbk::force_sym_wps<nbk::SymPacked<10>, 4, 2><<<grid, 256>>>(p); }});
+    vars.push_back(sym_variant<nbk::SymPacked<10>, 4, 2>("sym packed bpl10 w4 minw2 (B=2560)"));
+    vars.push_back({"sym bpl12 w4 waves_per_eu(2,2)", 3072, [](const nbk::SymParams& p, int grid) { nbk::force_sym_wps<nbk::SymPacked<12>, 4, 2><<<grid, 256>>>(p); }});
+    vars.push_back({"sym bpl8 w4 waves_per_eu(3,3)", 2048, [](const nbk::SymParams& p, int grid) { nbk::force_sym_wps<nbk::SymPacked<8>, 4, 3><<<grid, 256>>>(p); }});
     vars.push_back(sym_variant<nbk::SymPacked<8>, 4>("sym packed bpl8 w4 (B=2048)"));
+    vars.push_back({"sym bpl10 w4 SQUARE-only again", 2560, [](const nbk::SymParams& p, int grid) { nbk::force_sym_square<nbk::SymPacked<10>, 4><<<grid, 256>>>(p); }});
+    vars.push_back({"sym bpl8 w4 SQUARE-only", 2048, [](const nbk::SymParams& p, int grid) { nbk::force_sym_square<nbk::SymPacked<8>, 4><<<grid, 256>>>(p); }});
     vars.push_back(sym_variant<nbk::SymPacked<10>, 4>("sym packed bpl10 w4 (B=2560) again"));
     const double pairs = (double)n * n;
     const float t_ref = median_ms(one_sided, reps);
@@ -389,6 +392,9 @@ int main(int argc, char** argv)
                 double bytes = 0;
                 for (int I = 0; I < nb; ++I) bytes += (double)std::min(B, n - I * B) * (I + 1 + (nb - 1 - I + R - 1) / R) * 16;
                 const float ms_a = median_ms(shipped, reps), ms_r = median_ms(rows, reps), ms_a2 = median_ms(shipped, reps), ms_r2 = median_ms(rows, reps);
+                const float ms_fa = median_ms([&] { nbk::force_sym<nbk::SymPacked<BPL>, W><<<grid0, 64 * W>>>(sp); }, reps);
+                const float ms_fr = median_ms([&] { force_sym_rows<nbk::SymPacked<BPL>, W><<<grid, 64 * W>>>(rp); }, reps);
+                printf("        force alone: rows %.3f ms, shipped %.3f ms\n", ms_fr, ms_fa);
                 printf("  R=%d: %5d tasks, partial sums %.1f MB (%.0f%% of shipped) | rows %.3f / %.3f ms, shipped interleaved %.3f / %.3f ms | vs one-sided %.3g of max|a|, nonfinite %ld, vs truth %.3g\n",
                        R, grid, bytes / 1e6, bytes / ((double)nb * n * 16) * 100, ms_r, ms_r2, ms_a, ms_a2, dmax / scale, bad, err_vs_truth(a_sym));
                 fflush(stdout);
