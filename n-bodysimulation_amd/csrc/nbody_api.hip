@@ -595,6 +595,19 @@ int launch_sym_untimed(nbody_ctx* c, const SymShape& y0, const nbk::SymParams& p
     y.grid = ntasks >= 0 ? ntasks : y0.grid - p.task0;
     if (y.grid <= 0) return NBODY_OK;
     const int key = y.waves * 100 + y.bpl;
+    // one range against itself, no wrap-around: the square-only build of the same kernel (the default large-N shapes; measured
+    // 1.5-2.7 % faster than the general one at N = 262144, profiles/r03_symbench_rows_262144.txt)
+    const bool square = !p.rect && !p.wrap && p.i0 == p.j0 && p.ni == p.nj && p.slabs_i == p.slabs_j;
+    if (square && key == 410) {
+        nbk::force_sym_square<SymPacked<10>, 4><<<y.grid, 256, 0, c->stream>>>(p);
+        HIP_TRY(hipGetLastError());
+        return NBODY_OK;
+    }
+    if (square && key == 408) {
+        nbk::force_sym_square<SymPacked<8>, 4><<<y.grid, 256, 0, c->stream>>>(p);
+        HIP_TRY(hipGetLastError());
+        return NBODY_OK;
+    }
     switch (key) {
         case 410: nbk::force_sym<SymPacked<10>, 4><<<y.grid, 256, 0, c->stream>>>(p); break;
         case 408: nbk::force_sym<SymPacked<8>, 4><<<y.grid, 256, 0, c->stream>>>(p); break;

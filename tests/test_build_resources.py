@@ -80,3 +80,19 @@ def test_fp64_kernel_occupancy(kernels):
 def test_one_sided_default_shape(kernels):
     r = _get(kernels, "nbk::force_lds<nbk::MathPacked<4>, 2048, 8, 1, 0, 256>")
     assert r["LDS Size"] == 2 * 2048 * 16 and r["Occupancy"] >= 2, r
+
+
+def test_square_only_kernels_keep_the_occupancy_of_the_general_ones(nb, kernels):
+    for bpl in (10, 8):
+        r = _get(kernels, f"nbk::force_sym_square<nbk::SymPacked<{bpl}>, 4>")
+        assert r["Occupancy"] == nb.load().nbody_plan_symmetric_occupancy(bpl), r
+        assert r["LDS Size"] == 64 * 4 * bpl * 16
+
+
+@pytest.mark.parametrize("bpl", [2, 4, 8, 10])
+def test_balanced_run_kernels_fit_two_waves_per_simd(kernels, bpl):
+    """The balanced-run plan puts exactly two workers on every SIMD (kBalWavesPerSimd): every instantiation must allow that,
+    and its LDS (the I-side sums of the four workers of a workgroup) must leave room for two workgroups per CU."""
+    r = _get(kernels, f"nbk::force_sym_bal<nbk::SymPacked<{bpl}>, 4>")
+    assert r["Occupancy"] >= 2, r
+    assert r["LDS Size"] <= 4 * 64 * bpl * 16 + 64 and 2 * r["LDS Size"] <= 160 * 1024
