@@ -131,7 +131,7 @@ int nbody_ctx_set_symmetric_shape(nbody_ctx* ctx, int waves, int bodies_per_lane
 
 /* The symmetric kernel has two more decompositions for small and mid-size systems, where whole block pairs are too coarse a
  * unit for 1024 SIMDs. UNIT RUNS (about 45k ... 160k bodies): independent waves take runs of (I-block, one 64-body chunk)
- * units. BALANCED RUNS (about 7k ... 45k bodies, the reference's N_BODIES = 8192 among them): the same unit list cut at the
+ * units. BALANCED RUNS (about 6k ... 45k bodies, the reference's N_BODIES = 8192 among them): the same unit list cut at the
  * granularity of one rotation step, so that every resident wave gets the same number of steps; partial sums go to per-chunk
  * inboxes that one kernel sums and integrates. mode -1 (default): each is used where measurements prefer it (never when a waves
  * count was set through nbody_ctx_set_symmetric_shape); 0: never; 1: unit runs always (bodies_per_lane 8 or 10); 2: balanced

@@ -401,7 +401,7 @@ struct BalShape {
     size_t bytes;   // inbox workspace
 };
 
-constexpr int kBalMinAuto = 8192;    // FAST: balanced runs from this many bodies (below: the one-sided kernel) ...
+constexpr int kBalMinAuto = 6144;    // FAST: balanced runs from this many bodies (below: the one-sided kernel) ...
 constexpr int kBalMaxAuto = 45056;   // ... up to this many (above: unit runs / block pairs). Measured: profiles/r03_balbench_*.txt
 constexpr int kBalWavesPerSimd = 2, kBalWavesPerGroup = 4, kBalReduceWaves = 8;
 
@@ -709,7 +709,7 @@ const char* nbody_last_error(void) { return g_err; }
 
 const char* nbody_version(void)
 {
-    return "nbody_hip 0.3 gfx950 fast=symmetric-dpp(w4,bpl10)|symmetric-balanced-runs(7k-45k)|onesided-lds-packed(bpl4,tile2048,u8) strict=ieee-seq f64=symmetric-dpp(w4,bpl6)|lds";
+    return "nbody_hip 0.3 gfx950 fast=symmetric-dpp(w4,bpl10)|symmetric-balanced-runs(6k-45k)|onesided-lds-packed(bpl4,tile2048,u8) strict=ieee-seq f64=symmetric-dpp(w4,bpl6)|lds";
 }
 
 int nbody_device_count(int* count)

@@ -345,6 +345,23 @@ int main(int argc, char** argv)
                v.name.c_str(), ms, ms_force, pairs / ms * 1e3, 20 * pairs / ms * 1e3 / 157.3e12 * 100, dmax / scale, bad, err_vs_truth(a_sym), t2);
         fflush(stdout);
     }
+    // ---- what the last partial round costs: the square-only kernel on grids of whole and partial rounds of 512 resident workgroups
+    {
+        constexpr int W = 4, BPL = 10, B = 64 * W * BPL;
+        const int nb = (n + B - 1) / B;
+        if (nb >= 2 && nb <= max_slabs) {
+            nbk::SymParams sp{};
+            sp.x = dx; sp.slabs_i = slabs; sp.slabs_j = slabs; sp.ni = n; sp.nj = n; sp.i0 = 0; sp.j0 = 0; sp.wrap = 0; sp.nbi = nb; sp.nbj = nb;
+            sp.stride_i = n; sp.stride_j = n; sp.rect = 0; sp.eps2 = eps2;
+            const int full = nb * (nb - 1) / 2 + nb, npair = nb * (nb - 1) / 2;
+            printf("tail probe (square-only kernel, B=%d, %d tasks of which the last %d are diagonal): grid -> ms\n", B, full, nb);
+            for (int grid : {512, 1024, 2560, 4608, 5120, 5120 + 128, 5120 + 236, 5120 + 384, 5632, full, npair}) {
+                if (grid > full) continue;
+                const float ms = median_ms([&] { nbk::force_sym_square<nbk::SymPacked<BPL>, W><<<grid, 64 * W>>>(sp); }, reps);
+                printf("  grid %5d (%.2f rounds): %.3f ms\n", grid, grid / 512.0, ms);
+            }
+        }
+    }
     // ---- row-accumulating tasks (R consecutive J blocks per workgroup): bytes of partial sums and time against the shipped shape
     {
         constexpr int W = 4, BPL = 10, B = 64 * W * BPL;
