@@ -138,6 +138,15 @@ int nbody_ctx_set_symmetric_shape(nbody_ctx* ctx, int waves, int bodies_per_lane
  * runs always (bodies_per_lane 2, 4, 8 or 10; 0 = by size). Same pair arithmetic, same run-to-run reproducibility. */
 int nbody_ctx_set_symmetric_runs(nbody_ctx* ctx, int mode);
 
+/* Small systems (FAST kernel, up to 8192 bodies; mode -1, the default): nbody_step() runs ONE launch per step — a wave owns a few
+ * target bodies, its 64 lanes split the sources, the sum never leaves the wave and the integrate happens in the same kernel; no
+ * partial sums in memory, no second launch. Positions alternate between the caller's array and a spare one the context keeps (the
+ * result is always left in the caller's array: after an odd number of steps one device copy puts it there). One-sided arithmetic,
+ * same tolerances as the other fast kernels, bitwise reproducible run to run. mode 0: never (the LDS-tiled one-sided kernel +
+ * integrate, as nbody_accel_range + nbody_integrate_range compute it: bit-identical to that pair); mode 1: whenever the kernel is FAST,
+ * at any size. N = 8192, the reference's N_BODIES: 20.5 us per step against 25.7; N = 2048: 4.7 against 11.3. */
+int nbody_ctx_set_fused(nbody_ctx* ctx, int mode);
+
 /* The symmetric kernels keep one slab of partial sums per block of bodies (nb x n x 16 B: 412 MiB at N = 262144, 6.4 GiB at
  * N = 1048576, growing as N^2/B). The launch-shape choice only uses a symmetric decomposition whose workspace fits a cap:
  * min(96 GiB, half of the device memory that is free, `bytes` if non-zero); beyond it — or when the allocation itself fails —
@@ -373,7 +382,8 @@ int nbody_ctx_launch_info(nbody_ctx* ctx, int n_targets, int n_sources, int* jsp
                           int* lds_bytes);
 
 /* What nbody_step() does for n bodies: symmetric = 1 when the symmetric kernel runs on block pairs, 2 when it runs in
- * runs of chunk units, 3 in balanced runs of rotation steps (slabs = records per inbox), 0 for the one-sided kernel; block_bodies = bodies
+ * runs of chunk units, 3 in balanced runs of rotation steps (slabs = records per inbox), 0 for the one-sided kernel, -1 for the fused
+ * small-N step (one-sided arithmetic, force + integrate in one launch: slabs = 0, block_bodies = targets per workgroup); block_bodies = bodies
  * per block (symmetric) or per workgroup (one-sided); slabs = partial-sum slabs the integrate adds;
  * workgroups = grid size; evaluated_pairs = pair evaluations per step (n*n one-sided; about n*n/2 plus
  * the diagonal blocks symmetric — the interactions applied are n*n either way). Any out pointer may be NULL. */

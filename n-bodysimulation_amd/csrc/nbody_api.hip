@@ -99,6 +99,9 @@ struct nbody_ctx {
     size_t ws_limit = 0;       // caller's cap on ONE workspace in bytes (nbody_ctx_set_workspace_limit); 0 = automatic
     size_t ws_cap = (size_t)96 << 30;  // effective cap the shape choice honours: min(96 GiB, ws_limit, half of the device memory that
                                // was free), lowered further whenever an allocation fails (the next choice then needs less)
+    void* xalt = nullptr;      // the fused small-N step's second position array (positions alternate between it and the caller's)
+    size_t xalt_bytes = 0;
+    int fused = -1;            // fused small-N step: -1 where measurements prefer it (FAST, n <= kFusedMaxAuto), 0 never, 1 whenever FAST
     unsigned long long ws_tag = 0;     // which balanced-run layout the `slabs` workspace is cleared for (0 = none: any other user of it)
     bool ws_fail_above_limit = false;  // test hook: allocations above ws_limit are attempted and FAIL (out of memory) instead of
                                // being avoided by the shape choice
@@ -395,13 +398,74 @@ bool run_wanted(const nbody_ctx* c, int n, RunShape* out)
     return rc < 1.03 * bc;
 }
 
+// The FUSED small-N step (nbk::step_fused): a wave owns T targets, its lanes split the sources, the sum never leaves the wave and
+// the integrate happens in the same launch. One workgroup per CU measured best (tools/balbench.hip, profiles/r03_fused_*.txt):
+// T = 2 and N / (2 * 64 * CUs) waves per workgroup up to 16, T = 4 beyond.
+struct FusedShape {
+    int T, wv, tile, grid;
+};
+
+constexpr int kFusedMaxAuto = 8192;    // FAST: the fused step up to this many bodies — one workgroup of up to 16 waves per CU with two
+                                       // targets per wave; beyond, four targets per wave lose to the balanced runs (9216: 34.3 vs 29.4 us)
+
+bool fused_resolve(const nbody_ctx* c, int n, FusedShape* out)
+{
+    if (n < 1) return false;
+    FusedShape f{};
+    f.T = 2;
+    long waves = ((long)n + f.T - 1) / f.T;
+    long per = (waves + c->num_cu - 1) / c->num_cu;
+    if (per > 16) {
+        f.T = 4;
+        waves = ((long)n + f.T - 1) / f.T;
+        per = (waves + c->num_cu - 1) / c->num_cu;
+    }
+    int wv = (int)((per + 1) / 2 * 2);   // even, 2 .. 16 (built: 2, 4, 6, 8, 10, 12, 14, 16)
+    if (wv < 2) wv = 2;
+    if (wv > 16) wv = 16;
+    f.wv = wv;
+    static const int lpt[9] = {0, 16, 8, 6, 4, 4, 3, 3, 2};   // loads per thread per tile for wv = 2k: tiles of 2048 ... 2688 bodies
+    f.tile = 64 * wv * lpt[wv / 2];
+    f.grid = (int)((waves + wv - 1) / wv);
+    *out = f;
+    return true;
+}
+
+bool fused_wanted(const nbody_ctx* c, int n, FusedShape* out)
+{
+    if (c->kernel != NBODY_KERNEL_FAST || c->fused == 0) return false;
+    if (c->fused < 0 && (n > kFusedMaxAuto || c->sym_runs == 2)) return false;
+    int rw, rb;
+    fp32_shape_request(c, &rw, &rb);
+    if (c->fused < 0 && (rw || rb || c->tile || c->bpl || c->jsplit)) return false;   // an explicit shape request addresses the other kernels
+    return fused_resolve(c, n, out);
+}
+
+template <int T>
+int launch_fused_t(const FusedShape& f, const nbk::FusedParams& p, hipStream_t st)
+{
+    switch (f.wv) {
+        case 2: nbk::step_fused<T, 2, 2048><<<f.grid, 128, 0, st>>>(p); break;
+        case 4: nbk::step_fused<T, 4, 2048><<<f.grid, 256, 0, st>>>(p); break;
+        case 6: nbk::step_fused<T, 6, 2304><<<f.grid, 384, 0, st>>>(p); break;
+        case 8: nbk::step_fused<T, 8, 2048><<<f.grid, 512, 0, st>>>(p); break;
+        case 10: nbk::step_fused<T, 10, 2560><<<f.grid, 640, 0, st>>>(p); break;
+        case 12: nbk::step_fused<T, 12, 2304><<<f.grid, 768, 0, st>>>(p); break;
+        case 14: nbk::step_fused<T, 14, 2688><<<f.grid, 896, 0, st>>>(p); break;
+        case 16: nbk::step_fused<T, 16, 2048><<<f.grid, 1024, 0, st>>>(p); break;
+        default: return 1;
+    }
+    return 0;
+}
+
 // The BALANCED-run variant (nbk::force_sym_bal): workers of equal step counts, per-chunk inboxes, streaming reducer.
 struct BalShape {
     nbk::BalLayout y;
     size_t bytes;   // inbox workspace
 };
 
-constexpr int kBalMinAuto = 6144;    // FAST: balanced runs from this many bodies (below: the one-sided kernel) ...
+constexpr int kBalMinAuto = 6144;    // FAST: balanced runs from this many bodies (whole steps up to kFusedMaxAuto go to the fused step first;
+                                     // a square block of nbody_accel_range below this: the one-sided kernel) ...
 constexpr int kBalMaxAuto = 45056;   // ... up to this many (above: unit runs / block pairs). Measured: profiles/r03_balbench_*.txt
 constexpr int kBalWavesPerSimd = 2, kBalWavesPerGroup = 4, kBalReduceWaves = 8;
 
@@ -662,6 +726,16 @@ int launch_bal_reduce(nbody_ctx* c, const nbk::BalReduceParams& r)
     return NBODY_OK;
 }
 
+int launch_fused(nbody_ctx* c, const FusedShape& f, const nbk::FusedParams& p, bool timed)
+{
+    if (timed) if (int rc = time_mark(c)) return rc;
+    const int bad = f.T == 2 ? launch_fused_t<2>(f, p, c->stream) : launch_fused_t<4>(f, p, c->stream);
+    if (bad) return fail(NBODY_ERR_CONFIG, "no fused step kernel for T=%d waves=%d", f.T, f.wv);
+    HIP_TRY(hipGetLastError());
+    if (timed) return time_mark(c);
+    return NBODY_OK;
+}
+
 void run_params(nbk::RunParams* rp, const float4* x, int n, const RunShape& y, float4* slabs, float eps2)
 {
     *rp = nbk::RunParams{};
@@ -709,7 +783,7 @@ const char* nbody_last_error(void) { return g_err; }
 
 const char* nbody_version(void)
 {
-    return "nbody_hip 0.3 gfx950 fast=symmetric-dpp(w4,bpl10)|symmetric-balanced-runs(6k-45k)|onesided-lds-packed(bpl4,tile2048,u8) strict=ieee-seq f64=symmetric-dpp(w4,bpl6)|lds";
+    return "nbody_hip 0.3 gfx950 fast=symmetric-dpp(w4,bpl10)|symmetric-balanced-runs(8k-45k)|fused-step(<=8k)|onesided-lds-packed(bpl4,tile2048,u8) strict=ieee-seq f64=symmetric-dpp(w4,bpl6)|lds";
 }
 
 int nbody_device_count(int* count)
@@ -763,6 +837,7 @@ int nbody_ctx_destroy(nbody_ctx* c)
     DeviceGuard guard(c->device);
     if (c->slabs) (void)hipFree(c->slabs);
     if (c->xslabs) (void)hipFree(c->xslabs);
+    if (c->xalt) (void)hipFree(c->xalt);
     if (c->legacy_buf) (void)hipFree(c->legacy_buf);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -839,6 +914,14 @@ int nbody_ctx_set_symmetric_runs(nbody_ctx* c, int mode)
     if (int rc = check_ctx(c)) return rc;
     if (mode < -1 || mode > 2) return fail(NBODY_ERR_CONFIG, "runs mode must be -1 (auto), 0 (never), 1 (unit runs always) or 2 (balanced runs always)");
     c->sym_runs = mode;
+    return NBODY_OK;
+}
+
+int nbody_ctx_set_fused(nbody_ctx* c, int mode)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (mode < -1 || mode > 1) return fail(NBODY_ERR_CONFIG, "fused mode must be -1 (auto), 0 (never) or 1 (always)");
+    c->fused = mode;
     return NBODY_OK;
 }
 
@@ -936,7 +1019,7 @@ int nbody_ctx_launch_info(nbody_ctx* c, int n_targets, int n_sources, int* jspli
     SymShape y{};
     RunShape ry{};
     BalShape by{};
-    if (n_targets == n_sources && bal_wanted(c, n_targets, &by)) {
+    if (n_targets == n_sources && bal_wanted(c, n_targets, &by)) {   // (nbody_accel_range on a square block; a whole step of a small system is fused: nbody_ctx_step_info)
         if (jsplit) *jsplit = by.y.smax;
         if (blocks) *blocks = (by.y.nworkers + kBalWavesPerGroup - 1) / kBalWavesPerGroup;
         if (lds_bytes) *lds_bytes = kBalWavesPerGroup * 64 * by.y.bpl * (int)sizeof(float4);
@@ -969,6 +1052,15 @@ int nbody_ctx_step_info(nbody_ctx* c, int n, int* symmetric, int* block_bodies, 
     SymShape y{};
     RunShape ry{};
     BalShape by{};
+    FusedShape fs{};
+    if (fused_wanted(c, n, &fs)) {
+        if (symmetric) *symmetric = -1;  // one-sided arithmetic, force and integrate fused in one launch
+        if (block_bodies) *block_bodies = fs.T * fs.wv;
+        if (slabs) *slabs = 0;
+        if (workgroups) *workgroups = fs.grid;
+        if (evaluated_pairs) *evaluated_pairs = (double)n * (double)n;
+        return NBODY_OK;
+    }
     if (bal_wanted(c, n, &by)) {
         if (symmetric) *symmetric = 3;  // symmetric, in balanced runs of rotation steps
         if (block_bodies) *block_bodies = 64 * by.y.bpl;
@@ -1335,6 +1427,36 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
     if (n == 0 || steps == 0) return NBODY_OK;  // an empty system is a no-op, whatever the pointers
     if (!d_bodies || !d_accelerations || !d_velocity) return fail(NBODY_ERR_INVALID, "null device pointer");
     ON_DEVICE(c);
+    FusedShape fs{};
+    if (fused_wanted(c, n, &fs)) {
+        // small systems: one launch per step (force + integrate), positions alternating between the caller's array and a spare one
+        const size_t bytes = (size_t)n * sizeof(float4);
+        if (bytes > c->xalt_bytes) {
+            if (c->xalt) {
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                HIP_TRY(hipFree(c->xalt));
+                c->xalt = nullptr;
+                c->xalt_bytes = 0;
+            }
+            HIP_TRY(hipMalloc(&c->xalt, bytes));
+            c->xalt_bytes = bytes;
+        }
+        float4* const xa = reinterpret_cast<float4*>(d_bodies);
+        float4* const xb = static_cast<float4*>(c->xalt);
+        nbk::FusedParams fp{};
+        fp.v = reinterpret_cast<float4*>(d_velocity);
+        fp.a = reinterpret_cast<float4*>(d_accelerations);
+        fp.n = n;
+        fp.dt = c->dt;
+        fp.eps2 = c->eps2;
+        for (int k = 0; k < steps; ++k) {
+            fp.xin = (k & 1) ? xb : xa;
+            fp.xout = (k & 1) ? xa : xb;
+            if (int rc = launch_fused(c, fs, fp, c->timing)) return rc;
+        }
+        if (steps & 1) HIP_TRY(hipMemcpyAsync(xa, xb, bytes, hipMemcpyDeviceToDevice, c->stream));   // the result belongs in the caller's array
+        return NBODY_OK;
+    }
     SymShape y{};
     RunShape ry{};
     BalShape by{};

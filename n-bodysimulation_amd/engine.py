@@ -97,6 +97,10 @@ class Context:
         2 balanced (step-granular) runs always."""
         check(self._lib.nbody_ctx_set_symmetric_runs(self._h, mode))
 
+    def set_fused(self, mode: int) -> None:
+        """The fused small-N step (force + integrate in one launch): -1 where measurements prefer it, 0 never, 1 always (FAST)."""
+        check(self._lib.nbody_ctx_set_fused(self._h, mode))
+
     def set_workspace_limit(self, nbytes: int = 0, fail_above: bool = False) -> None:
         """Cap on one partial-sum workspace (0 = automatic: min(96 GiB, half of the free device memory)). Shapes that need
         more are not chosen; the step falls back towards the one-sided kernel. fail_above=True is the test hook of nbody.h."""
@@ -125,8 +129,8 @@ class Context:
     def _info(self, fn, *args) -> dict:
         sym, blk, slabs, wgs, ev = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_double()
         check(fn(self._h, *args, C.byref(sym), C.byref(blk), C.byref(slabs), C.byref(wgs), C.byref(ev)))
-        return {"symmetric": bool(sym.value), "runs": sym.value == 2, "balanced": sym.value == 3, "block_bodies": blk.value,
-                "slabs": slabs.value, "workgroups": wgs.value, "evaluated_pairs": ev.value}
+        return {"symmetric": sym.value > 0, "runs": sym.value == 2, "balanced": sym.value == 3, "fused": sym.value == -1,
+                "block_bodies": blk.value, "slabs": slabs.value, "workgroups": wgs.value, "evaluated_pairs": ev.value}
 
     def step_info_f64(self, n: int) -> dict:
         """What nbody_step_f64 launches for n bodies."""

@@ -96,3 +96,15 @@ def test_balanced_run_kernels_fit_two_waves_per_simd(kernels, bpl):
     r = _get(kernels, f"nbk::force_sym_bal<nbk::SymPacked<{bpl}>, 4>")
     assert r["Occupancy"] >= 2, r
     assert r["LDS Size"] <= 4 * 64 * bpl * 16 + 64 and 2 * r["LDS Size"] <= 160 * 1024
+
+
+def test_fused_step_kernels_fit_one_workgroup_per_cu(kernels):
+    """The fused small-N step runs one workgroup of 2 ... 16 waves per CU: every instantiation must fit (VGPRs of 16 waves:
+    at most 128 each; LDS: the double-buffered source tile), without scratch."""
+    names = [k for k in kernels if k.startswith("nbk::step_fused<")]
+    assert len(names) == 16, names
+    for name in names:
+        r = kernels[name]
+        t, wv, tile = (int(v) for v in name[len("nbk::step_fused<"):-1].split(","))
+        assert r["LDS Size"] == 2 * tile * 16 and r["LDS Size"] <= 160 * 1024, (name, r)
+        assert r["Occupancy"] * 4 >= wv, (name, r)            # all waves of the workgroup resident on the CU's four SIMDs

@@ -442,8 +442,8 @@ def test_reference_shipped_size_fast_vs_literal_reference(nb, oracle, kernel):
     x0 = _ref_n8192_start(nb)
     k = {"fast": nb.KERNEL_FAST, "onesided": nb.KERNEL_ONESIDED, "symmetric": nb.KERNEL_SYMMETRIC}[kernel]
     sim = nb.engine.Simulation(x0, dt=0.1, eps2=0.002, kernel=k)
-    info = sim.ctx.step_info(8192)     # FAST at this size: the balanced-run symmetric variant; SYMMETRIC: block pairs; ONESIDED: one-sided
-    assert info["symmetric"] == (kernel != "onesided") and info["balanced"] == (kernel == "fast")
+    info = sim.ctx.step_info(8192)     # FAST at this size: the fused one-launch step; SYMMETRIC: block pairs; ONESIDED: LDS-tiled one-sided
+    assert info["symmetric"] == (kernel == "symmetric") and info["fused"] == (kernel == "fast")
     xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
     oracle.step_jacobi(xo, ao, vo, dt=0.1, eps2=0.002, steps=1)
     sim.run(1)
@@ -1018,18 +1018,21 @@ def test_balanced_runs_vs_oracle(nb, oracle, n, bpl, init):
     assert np.array_equal(a, a2) and np.array_equal(x, x2) and np.array_equal(v, v2)
 
 
-def test_balanced_runs_are_what_fast_picks_at_the_reference_size(nb, oracle):
-    """FAST at the reference's shipped N_BODIES = 8192 (constants.h:13), at 16384 and at 32768 is the balanced-run variant; 4096 stays
-    one-sided, 65536 goes to unit runs. Ten steps at N = 8192 from the reference's kind of initial conditions against the Jacobi
+def test_balanced_runs_are_what_fast_picks_at_mid_sizes(nb, oracle):
+    """FAST from 12288 to 32768 bodies is the balanced-run variant (up to 10240 the fused step, 65536 unit runs); without the fused step
+    it is what runs at the reference's shipped N_BODIES = 8192 (constants.h:13). Ten steps at N = 8192 from the reference's kind of initial conditions against the Jacobi
     oracle, and the square block of nbody_accel_range (accumulate on and off) through the same kernels."""
     ctx = nb.engine.Context()
-    assert not ctx.step_info(4096)["symmetric"]
-    for n in (8192, 16384, 32768):
+    for n in (1024, 4096, 7168, 8192):
+        assert ctx.step_info(n)["fused"] and not ctx.step_info(n)["symmetric"], n      # whole steps of small systems: one launch
+    for n in (9216, 12288, 16384, 32768):
         assert ctx.step_info(n)["balanced"], n
     assert ctx.step_info(65536)["runs"] and ctx.step_info(262144)["symmetric"] and not ctx.step_info(262144)["balanced"]
     n = 8192
     x0 = nb.engine.seeded_bodies(n, 0, 3)
     sim = nb.engine.Simulation(x0, dt=0.1, eps2=0.002)
+    sim.ctx.set_fused(0)                                          # without the fused step FAST is the balanced-run variant here
+    assert sim.ctx.step_info(n)["balanced"]
     sim.run(10)
     x, v, a = sim.state()
     xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
@@ -1074,3 +1077,72 @@ def test_balanced_runs_workspace_is_recleared_after_other_users(nb, oracle):
     assert torch.equal(a1, a2)
     truth = oracle.accel_range(x0, 0, 1024, 0, n, eps2=0.002, f64acc=True)
     assert np.abs(a2.cpu().numpy()[:1024] - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 1e-5
+
+
+# ---- the fused small-N step: force + integrate in ONE launch, positions alternating between two arrays ---------------------
+
+@pytest.mark.parametrize("n,init,steps", [(1, 0, 3), (2, 0, 2), (63, 1, 3), (64, 0, 1), (129, 1, 4), (1000, 0, 5), (1024, 1, 100), (2048, 0, 1),
+                                          (3001, 1, 1), (4096, 0, 1), (5000, 1, 2), (8192, 0, 1), (8192, 0, 3), (8192, 1, 10), (7777, 1, 3),
+                                          (8192, 1, 1)])
+def test_fused_step_vs_oracle(nb, oracle, n, init, steps):
+    """nbody_step through the fused kernel (FAST, n <= 8192): every workgroup shape the size rule picks, sizes that are not
+    multiples of anything, odd and even step counts (the result must end in the caller's array either way), against the Jacobi
+    oracle: accelerations <= 1e-5 of max|a|, positions within the fast tolerances, mass and w lanes preserved, bitwise
+    run-to-run reproducibility; and equal (to tolerance) to the two-kernel path it replaces."""
+    x0 = nb.engine.seeded_bodies(n, init, 31)
+    dt = 0.1 if init == 0 else 0.01
+    scale = 1e5 if init == 0 else 1.0
+    sim = nb.engine.Simulation(x0, dt=dt, eps2=0.002)
+    assert sim.ctx.step_info(n)["fused"]
+    sim.run(steps)
+    x, v, a = sim.state()
+    xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
+    oracle.step_jacobi(xo, ao, vo, dt=dt, eps2=0.002, steps=steps)
+    amax = max(np.abs(ao[:, :3]).max(), 1e-30)
+    tol_x = 1e-6 if steps <= 5 else 1e-5
+    assert np.abs(x - xo)[:, :3].max() / scale <= tol_x
+    if steps == 1:     # (later steps evaluate the force at positions that already differ in the last bits: close pairs amplify that)
+        assert np.abs(a - ao)[:, :3].max() / amax <= 1e-5
+    assert np.array_equal(x[:, 3], x0[:, 3]) and np.all(a[:, 3] == 0) and np.all(v[:, 3] == 0)
+    again = nb.engine.Simulation(x0, dt=dt, eps2=0.002)
+    again.run(steps)
+    x2, v2, a2 = again.state()
+    assert np.array_equal(x, x2) and np.array_equal(v, v2) and np.array_equal(a, a2)
+    plain = nb.engine.Simulation(x0, dt=dt, eps2=0.002)
+    plain.ctx.set_fused(0)
+    assert not plain.ctx.step_info(n)["fused"]
+    plain.run(steps)
+    xp, vp, ap = plain.state()
+    assert np.abs(x - xp)[:, :3].max() / scale <= tol_x
+
+
+def test_fused_step_split_calls_and_the_simulate_boundary(nb, oracle):
+    """Seven steps as 1 + 2 + 4 separate calls equal seven in one call bit for bit (the spare array never leaks into the result);
+    simulate() — one synchronous step per call, the reference's boundary — takes the same path; mode 1 forces the fused step at a
+    size where FAST would not choose it."""
+    n = 3000
+    x0 = nb.engine.seeded_bodies(n, 1, 8)
+    a_sim = nb.engine.Simulation(x0, dt=0.01, eps2=0.002)
+    a_sim.run(7)
+    b_sim = nb.engine.Simulation(x0, dt=0.01, eps2=0.002)
+    for k in (1, 2, 4):
+        b_sim.run(k)
+    for p, q in zip(a_sim.state(), b_sim.state()):
+        assert np.array_equal(p, q)
+    dev = torch.device("cuda", 0)
+    x = torch.from_numpy(nb.engine.seeded_bodies(n, 0, 9)).to(dev)
+    v, a = torch.zeros_like(x), torch.zeros_like(x)
+    x_start = x.cpu().numpy()
+    for _ in range(3):
+        nb.engine.simulate(x, a, v)                               # DT 0.1 / EPS2 0.002, default context, synchronous
+    xo, vo, ao = x_start.copy(), np.zeros_like(x_start), np.zeros_like(x_start)
+    oracle.step_jacobi(xo, ao, vo, dt=0.1, eps2=0.002, steps=3)
+    assert np.abs(x.cpu().numpy() - xo)[:, :3].max() / 1e5 <= 1e-6
+    n2 = 20000
+    big = nb.engine.Simulation(nb.engine.seeded_bodies(n2, 1, 4), dt=0.01, eps2=0.002)
+    assert big.ctx.step_info(n2)["balanced"]
+    big.ctx.set_fused(1)
+    assert big.ctx.step_info(n2)["fused"]
+    big.run(1)
+    truth = oracle.accel_range(nb.engine.seeded_bodies(n2, 1, 4), 0, 512, 0, n2, eps2=0.002, f64acc=True)
+    assert np.abs(big.state()[2][:512] - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 1e-5

@@ -32,9 +32,13 @@ def test_one_rank_nccl_group_equals_single_gpu(nb):
         sh.step(4)
         xs, vs, as_ = sh.gather_state()
         sim = nb.engine.Simulation(x0, dt=0.01, eps2=0.002)
+        sim.ctx.set_fused(0)             # the shard builds its step from nbody_accel_range + nbody_integrate_range: the two-kernel path
         sim.run(4)
         x, v, a = sim.state()
         assert np.array_equal(xs, x) and np.array_equal(vs, v) and np.array_equal(as_, a)   # one rank == nbody_step, bit for bit
+        fused = nb.engine.Simulation(x0, dt=0.01, eps2=0.002)                               # what nbody_step runs by default at this size
+        fused.run(4)
+        assert np.abs(fused.state()[0] - x)[:, :3].max() <= 1e-6
         # the RCCL calls of the multi-rank path, as far as one rank can exercise them: the in-place
         # all_gather_into_tensor on the library's communication stream, MAX all-reduce, barrier
         before = sh.x.clone()

@@ -165,6 +165,48 @@ int main(int argc, char** argv)
     double scale = 0;
     for (int i = 0; i < n; ++i) scale = std::max({scale, (double)std::fabs(a_ref[i].x), (double)std::fabs(a_ref[i].y), (double)std::fabs(a_ref[i].z)});
 
+    // ---- the fused small-N step: one launch per step, positions alternate between two arrays
+    {
+        float4* dx2;
+        CK(hipMalloc(&dx2, (size_t)n * 16));
+        CK(hipMemcpy(dx2, dx, (size_t)n * 16, hipMemcpyDeviceToDevice));
+        struct Var { const char* name; int T, WV, TILE; std::function<void(const nbk::FusedParams&)> launch; };
+        std::vector<Var> vars;
+#define FUSED(T_, WV_, TILE_) vars.push_back({"fused T" #T_ " wv" #WV_ " tile" #TILE_, T_, WV_, TILE_, [&](const nbk::FusedParams& q) { \
+            nbk::step_fused<T_, WV_, TILE_><<<(n + T_ * WV_ - 1) / (T_ * WV_), 64 * WV_>>>(q); }})
+        FUSED(2, 4, 1024); FUSED(2, 4, 2048); FUSED(2, 8, 2048); FUSED(2, 8, 4096); FUSED(2, 6, 1536); FUSED(2, 6, 3072); FUSED(2, 12, 3072); FUSED(2, 16, 2048);
+        FUSED(2, 16, 4096); FUSED(4, 4, 1024); FUSED(4, 4, 2048); FUSED(4, 8, 2048); FUSED(4, 8, 4096); FUSED(4, 6, 3072); FUSED(2, 10, 2560); FUSED(2, 5, 2560);
+        for (auto& v : vars) {
+            nbk::FusedParams q{};
+            q.xin = dx; q.xout = dx2; q.v = dv; q.a = da; q.n = n; q.dt = 0.0f; q.eps2 = eps2;
+            CK(hipMemset(da, 0xff, (size_t)n * 16));
+            v.launch(q);
+            CK(hipGetLastError());
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(a_bal.data(), da, (size_t)n * 16, hipMemcpyDeviceToHost));
+            double dmax = 0;
+            long bad = 0;
+            for (int i = 0; i < n; ++i) {
+                const double e = std::max({std::fabs((double)a_ref[i].x - a_bal[i].x), std::fabs((double)a_ref[i].y - a_bal[i].y),
+                                           std::fabs((double)a_ref[i].z - a_bal[i].z)});
+                if (!(e <= 1e30)) ++bad; else dmax = std::max(dmax, e);
+            }
+            int flip = 0;
+            auto step = [&] {   // ping-pong, as nbody_step does
+                nbk::FusedParams r = q;
+                r.xin = flip ? dx2 : dx; r.xout = flip ? dx : dx2;
+                flip ^= 1;
+                v.launch(r);
+            };
+            const double t = us_per_call(step, steps);
+            printf("%-26s: %d waves | %.2f us/step = %.3e pairs/s (%.1f%% of 157.3 TF) | vs one-sided %.2g of max|a|, nonfinite %ld, vs truth %.2g\n", v.name,
+                   (n + v.T - 1) / v.T, t, pairs / t * 1e6, 20 * pairs / t * 1e6 / 157.3e12 * 100, dmax / scale, bad, err_vs_truth(a_bal));
+            fflush(stdout);
+        }
+        CK(hipFree(dx2));
+    }
+    if (getenv("BALBENCH_FUSED_ONLY")) return 0;
+
     for (int bpl : {2, 4, 8, 10}) {
         for (int wps : {2, 3, 4}) {
           for (int wv : {1, 4, 8}) {
