@@ -441,6 +441,27 @@ bool fused_wanted(const nbody_ctx* c, int n, FusedShape* out)
     return fused_resolve(c, n, out);
 }
 
+// the fused step's spare position array
+int ensure_xalt(nbody_ctx* c, int n)
+{
+    const size_t bytes = (size_t)n * sizeof(float4);
+    if (bytes <= c->xalt_bytes) return NBODY_OK;
+    if (c->xalt) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipFree(c->xalt));
+        c->xalt = nullptr;
+        c->xalt_bytes = 0;
+    }
+    const hipError_t e = hipMalloc(&c->xalt, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        c->xalt = nullptr;
+        return fail(NBODY_ERR_NOMEM, "cannot allocate the fused step's spare position array (%zu bytes): %s", bytes, hipGetErrorString(e));
+    }
+    c->xalt_bytes = bytes;
+    return NBODY_OK;
+}
+
 template <int T>
 int launch_fused_t(const FusedShape& f, const nbk::FusedParams& p, hipStream_t st)
 {
@@ -948,6 +969,10 @@ int nbody_ctx_reserve(nbody_ctx* c, int n_targets)
     if (n_targets < 0) return fail(NBODY_ERR_INVALID, "n_targets < 0");
     ON_DEVICE(c);
     refresh_ws_cap(c);
+    {
+        FusedShape fs{};
+        if (fused_wanted(c, n_targets, &fs)) (void)ensure_xalt(c, n_targets);   // whole steps of this size run the fused kernel; the workspace below
+    }                                                                           // still serves nbody_accel_range on such a block
     for (int attempt = 0;; ++attempt) {
         BalShape by{};
         if (bal_wanted(c, n_targets, &by)) {
@@ -1428,19 +1453,9 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
     if (!d_bodies || !d_accelerations || !d_velocity) return fail(NBODY_ERR_INVALID, "null device pointer");
     ON_DEVICE(c);
     FusedShape fs{};
-    if (fused_wanted(c, n, &fs)) {
+    if (fused_wanted(c, n, &fs) && ensure_xalt(c, n) == NBODY_OK) {   // (no spare array to be had: the two-kernel paths below)
         // small systems: one launch per step (force + integrate), positions alternating between the caller's array and a spare one
         const size_t bytes = (size_t)n * sizeof(float4);
-        if (bytes > c->xalt_bytes) {
-            if (c->xalt) {
-                HIP_TRY(hipStreamSynchronize(c->stream));
-                HIP_TRY(hipFree(c->xalt));
-                c->xalt = nullptr;
-                c->xalt_bytes = 0;
-            }
-            HIP_TRY(hipMalloc(&c->xalt, bytes));
-            c->xalt_bytes = bytes;
-        }
         float4* const xa = reinterpret_cast<float4*>(d_bodies);
         float4* const xb = static_cast<float4*>(c->xalt);
         nbk::FusedParams fp{};

@@ -174,8 +174,13 @@ int main(int argc, char** argv)
         std::vector<Var> vars;
 #define FUSED(T_, WV_, TILE_) vars.push_back({"fused T" #T_ " wv" #WV_ " tile" #TILE_, T_, WV_, TILE_, [&](const nbk::FusedParams& q) { \
             nbk::step_fused<T_, WV_, TILE_><<<(n + T_ * WV_ - 1) / (T_ * WV_), 64 * WV_>>>(q); }})
+        if (getenv("BALBENCH_FUSED_TWO_PER_CU")) {   // sizes above 8192: two workgroups per CU
+            FUSED(2, 10, 1280); FUSED(2, 10, 2560); FUSED(2, 12, 1536); FUSED(2, 12, 2304); FUSED(2, 16, 2048); FUSED(2, 14, 1792); FUSED(2, 8, 2048); FUSED(4, 10, 2560);
+            FUSED(4, 6, 2304); FUSED(4, 8, 2048);
+        } else {
         FUSED(2, 4, 1024); FUSED(2, 4, 2048); FUSED(2, 8, 2048); FUSED(2, 8, 4096); FUSED(2, 6, 1536); FUSED(2, 6, 3072); FUSED(2, 12, 3072); FUSED(2, 16, 2048);
         FUSED(2, 16, 4096); FUSED(4, 4, 1024); FUSED(4, 4, 2048); FUSED(4, 8, 2048); FUSED(4, 8, 4096); FUSED(4, 6, 3072); FUSED(2, 10, 2560); FUSED(2, 5, 2560);
+        }
         for (auto& v : vars) {
             nbk::FusedParams q{};
             q.xin = dx; q.xout = dx2; q.v = dv; q.a = da; q.n = n; q.dt = 0.0f; q.eps2 = eps2;
