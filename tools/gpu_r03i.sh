@@ -3,7 +3,7 @@
 # PMC passes of the N=262144 launch shape, kernel stats at small N
 set -o pipefail
 REPO=$PWD
-OUT=$REPO/gpurun_out/r03_i
+OUT=$REPO/gpurun_out/r03_r
 mkdir -p $OUT
 export TMPDIR=/tmp
 timeout -k 10 1100 python -m pytest tests -m gpu -q -x > $OUT/pytest_gpu.txt 2>&1; rc=$?
