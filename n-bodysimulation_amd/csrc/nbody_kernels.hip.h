@@ -1256,7 +1256,7 @@ struct FusedParams {
     float dt, eps2;
 };
 
-template <int T, int WV, int TILE>
+template <int T, int WV, int TILE, int UNROLL = 8>
 __global__ void __launch_bounds__(64 * WV) step_fused(const FusedParams p)
 {
     static_assert(T % 2 == 0 && TILE % (64 * WV) == 0, "packed targets, whole loads per thread");
@@ -1295,7 +1295,7 @@ __global__ void __launch_bounds__(64 * WV) step_fused(const FusedParams p)
         if (jt + TILE < p.n) fetch(jt + TILE);
         const int left = p.n - jt;
         if (left >= TILE) {
-#pragma unroll 4
+#pragma unroll UNROLL
             for (int jj = 0; jj < TILE / 64; ++jj) t.pair(sh[buf][jj * 64 + lane]);   // this lane's sources of the tile
         } else {   // the last tile may be short: only its occupied 64-body rows
             const int rows = (left + 63) / 64;

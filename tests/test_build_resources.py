@@ -105,6 +105,6 @@ def test_fused_step_kernels_fit_one_workgroup_per_cu(kernels):
     assert len(names) == 16, names
     for name in names:
         r = kernels[name]
-        t, wv, tile = (int(v) for v in name[len("nbk::step_fused<"):-1].split(","))
+        t, wv, tile = (int(v) for v in name[len("nbk::step_fused<"):-1].split(",")[:3])     # <targets per wave, waves, tile, unroll>
         assert r["LDS Size"] == 2 * tile * 16 and r["LDS Size"] <= 160 * 1024, (name, r)
         assert r["Occupancy"] * 4 >= wv, (name, r)            # all waves of the workgroup resident on the CU's four SIMDs

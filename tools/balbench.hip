@@ -174,7 +174,11 @@ int main(int argc, char** argv)
         std::vector<Var> vars;
 #define FUSED(T_, WV_, TILE_) vars.push_back({"fused T" #T_ " wv" #WV_ " tile" #TILE_, T_, WV_, TILE_, [&](const nbk::FusedParams& q) { \
             nbk::step_fused<T_, WV_, TILE_><<<(n + T_ * WV_ - 1) / (T_ * WV_), 64 * WV_>>>(q); }})
-        if (getenv("BALBENCH_FUSED_TWO_PER_CU")) {   // sizes above 8192: two workgroups per CU
+        if (getenv("BALBENCH_FUSED_UNROLL")) {
+#define FUSEDU(T_, WV_, TILE_, U_) vars.push_back({"fused T" #T_ " wv" #WV_ " tile" #TILE_ " unroll" #U_, T_, WV_, TILE_, [&](const nbk::FusedParams& q) { \
+            nbk::step_fused<T_, WV_, TILE_, U_><<<(n + T_ * WV_ - 1) / (T_ * WV_), 64 * WV_>>>(q); }})
+            FUSEDU(2, 16, 2048, 2); FUSEDU(2, 16, 2048, 4); FUSEDU(2, 16, 2048, 8); FUSEDU(2, 16, 2048, 16); FUSEDU(2, 16, 1024, 4); FUSEDU(2, 16, 1024, 8); FUSEDU(2, 16, 2048, 4);
+        } else if (getenv("BALBENCH_FUSED_TWO_PER_CU")) {   // sizes above 8192: two workgroups per CU
             FUSED(2, 10, 1280); FUSED(2, 10, 2560); FUSED(2, 12, 1536); FUSED(2, 12, 2304); FUSED(2, 16, 2048); FUSED(2, 14, 1792); FUSED(2, 8, 2048); FUSED(4, 10, 2560);
             FUSED(4, 6, 2304); FUSED(4, 8, 2048);
         } else {
