@@ -465,15 +465,17 @@ int ensure_xalt(nbody_ctx* c, int n)
 template <int T>
 int launch_fused_t(const FusedShape& f, const nbk::FusedParams& p, hipStream_t st)
 {
+    // <targets per wave, waves per workgroup, tile, unroll of the per-lane source loop>: the unroll measured better per shape
+    // (profiles/r03_smalln_probe.jsonl; N = 8192: 21.07 us at 4, 20.36 at 8; N = 4096: 7.99 at 4, 8.72 at 8)
     switch (f.wv) {
-        case 2: nbk::step_fused<T, 2, 2048><<<f.grid, 128, 0, st>>>(p); break;
-        case 4: nbk::step_fused<T, 4, 2048><<<f.grid, 256, 0, st>>>(p); break;
-        case 6: nbk::step_fused<T, 6, 2304><<<f.grid, 384, 0, st>>>(p); break;
-        case 8: nbk::step_fused<T, 8, 2048><<<f.grid, 512, 0, st>>>(p); break;
-        case 10: nbk::step_fused<T, 10, 2560><<<f.grid, 640, 0, st>>>(p); break;
-        case 12: nbk::step_fused<T, 12, 2304><<<f.grid, 768, 0, st>>>(p); break;
-        case 14: nbk::step_fused<T, 14, 2688><<<f.grid, 896, 0, st>>>(p); break;
-        case 16: nbk::step_fused<T, 16, 2048><<<f.grid, 1024, 0, st>>>(p); break;
+        case 2: nbk::step_fused<T, 2, 2048, 8><<<f.grid, 128, 0, st>>>(p); break;
+        case 4: nbk::step_fused<T, 4, 2048, 8><<<f.grid, 256, 0, st>>>(p); break;
+        case 6: nbk::step_fused<T, 6, 2304, 4><<<f.grid, 384, 0, st>>>(p); break;
+        case 8: nbk::step_fused<T, 8, 2048, 4><<<f.grid, 512, 0, st>>>(p); break;
+        case 10: nbk::step_fused<T, 10, 2560, 8><<<f.grid, 640, 0, st>>>(p); break;
+        case 12: nbk::step_fused<T, 12, 2304, 4><<<f.grid, 768, 0, st>>>(p); break;
+        case 14: nbk::step_fused<T, 14, 2688, 8><<<f.grid, 896, 0, st>>>(p); break;
+        case 16: nbk::step_fused<T, 16, 2048, 8><<<f.grid, 1024, 0, st>>>(p); break;
         default: return 1;
     }
     return 0;
