@@ -65,9 +65,11 @@ enum {
     /* FAST / ONESIDED / SYMMETRIC evaluate rsq(d)^3, which does not overflow there: they keep the physically correct    */
     /* term m/r^2 the reference drops (<= 1e9/(2.6e6)^2 = 1.5e-4 with the reference's masses, ~1e-7 of a typical max|a|); */
     /* results stay finite for any finite input (tests/test_gpu_parity.py::test_fast_kernels_at_the_overflow_corner).    */
-    NBODY_KERNEL_FAST = 0,      /* packed fp32, v_rsq_f32, fma; tolerance-level parity. A whole step (or a  */
-                                /* square block of nbody_accel_range) of >= 12288 bodies runs the SYMMETRIC */
-                                /* kernel, anything else the ONESIDED one                                   */
+    NBODY_KERNEL_FAST = 0,      /* packed fp32, v_rsq_f32, fma; tolerance-level parity. The library picks   */
+                                /* the decomposition by size: whole steps up to 8192 bodies run the FUSED     */
+                                /* one-launch step (one-sided arithmetic), from there — and square blocks of  */
+                                /* nbody_accel_range from 6144 bodies — the SYMMETRIC kernel (balanced runs,  */
+                                /* unit runs, block pairs); anything else the ONESIDED one                   */
     NBODY_KERNEL_STRICT = 1,    /* the reference's operation order with IEEE sqrt/div, no fma contraction,  */
                                 /* j==i skipped: bit-identical to validation.cpp's arithmetic taken in      */
                                 /* Jacobi order                                                             */
@@ -144,7 +146,7 @@ int nbody_ctx_set_symmetric_runs(nbody_ctx* ctx, int mode);
  * result is always left in the caller's array: after an odd number of steps one device copy puts it there). One-sided arithmetic,
  * same tolerances as the other fast kernels, bitwise reproducible run to run. mode 0: never (the LDS-tiled one-sided kernel +
  * integrate, as nbody_accel_range + nbody_integrate_range compute it: bit-identical to that pair); mode 1: whenever the kernel is FAST,
- * at any size. N = 8192, the reference's N_BODIES: 20.5 us per step against 25.7; N = 2048: 4.7 against 11.3. */
+ * at any size. N = 8192, the reference's N_BODIES: 20.5 us per step against 25.7; N = 2048: 4.2 against 11.4. */
 int nbody_ctx_set_fused(nbody_ctx* ctx, int mode);
 
 /* The symmetric kernels keep one slab of partial sums per block of bodies (nb x n x 16 B: 412 MiB at N = 262144, 6.4 GiB at

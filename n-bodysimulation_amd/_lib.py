@@ -18,7 +18,7 @@ ERR_HIP = 2
 ERR_CONFIG = 3
 ERR_NOMEM = 4
 
-KERNEL_FAST = 0       # symmetric kernel for whole steps / square blocks of >= 12288 bodies, else one-sided
+KERNEL_FAST = 0       # by size: fused one-launch step (<= 8192 bodies), symmetric kernel (balanced runs / unit runs / block pairs) above
 KERNEL_STRICT = 1
 KERNEL_ONESIDED = 2   # fast arithmetic, every target evaluates all N sources
 KERNEL_SYMMETRIC = 3  # fast arithmetic, every unordered pair once (Newton's third law)
