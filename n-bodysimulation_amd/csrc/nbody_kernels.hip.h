@@ -767,8 +767,8 @@ __global__ void __launch_bounds__(64 * W, 1) force_sym_square(const SymParamsT<t
     }
 }
 
-// The same kernel compiled for EXACTLY WPS waves per SIMD (amdgpu_waves_per_eu): the register allocator may then use the whole
-// budget of that occupancy (256 VGPRs at two waves) instead of stopping at its own estimate (196 for SymPacked<10>).
+// The same kernel compiled for EXACTLY WPS waves per SIMD (amdgpu_waves_per_eu). Measured alternative, tools/symbench.hip only: it does
+// not change the register allocation (200 VGPRs either way) and is within noise of the plain build (profiles/r03_symbench_rows_262144.txt).
 template <class M, int W, int WPS>
 __global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
 force_sym_wps(const SymParamsT<typename M::V4, typename M::S> p)
@@ -1024,7 +1024,7 @@ __device__ __forceinline__ void sym_row_range(M& t, const typename M::V4& bj, ty
 }
 
 template <class M, int WV>
-__global__ void __launch_bounds__(64 * WV) force_sym_bal(const BalParams p)
+__device__ __forceinline__ void force_sym_bal_body(const BalParams& p)
 {
     constexpr int BPL = M::BPL;
     __shared__ float4 sh[WV][64 * BPL];
@@ -1125,6 +1125,21 @@ __global__ void __launch_bounds__(64 * WV) force_sym_bal(const BalParams p)
         const int c = my_last_row * BPL + k;
         if (c < y.ncht) p.inbox[((size_t)c * y.smax + rec) * 64 + lane] = a;
     }
+}
+
+template <class M, int WV>
+__global__ void __launch_bounds__(64 * WV) force_sym_bal(const BalParams p)
+{
+    force_sym_bal_body<M, WV>(p);
+}
+
+// The same kernel compiled for exactly WPS waves per SIMD (the register allocator then fits that occupancy). Measured alternative,
+// tools/balbench.hip only: 8 bodies per lane at three waves per SIMD (168 VGPRs, 8 spilled dwords) is 1-5 % SLOWER than two waves
+// at 12288 ... 32768 bodies (more workers, more records) — profiles/r03_balbench_wps3.txt.
+template <class M, int WV, int WPS>
+__global__ void __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WPS, WPS))) force_sym_bal_wps(const BalParams p)
+{
+    force_sym_bal_body<M, WV>(p);
 }
 
 // Sum of one 64-body chunk's inbox (one workgroup of 64*P threads per chunk; wave p takes records p, p + P, ...), then either the

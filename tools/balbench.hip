@@ -62,9 +62,14 @@ static double us_per_call(const std::function<void()>& f, int steps, int reps = 
 
 template <class M, int WV>
 static void launch_bal_wv(const nbk::BalParams& p) { nbk::force_sym_bal<M, WV><<<(p.y.nworkers + WV - 1) / WV, 64 * WV>>>(p); }
+static int g_bal_wps3 = 0;
 template <class M>
 static void launch_bal(const nbk::BalParams& p)
 {
+    if (g_bal_wps3 && p.y.wv == 4) {   // the build for exactly three waves per SIMD
+        nbk::force_sym_bal_wps<M, 4, 3><<<(p.y.nworkers + 3) / 4, 256>>>(p);
+        return;
+    }
     switch (p.y.wv) {
         case 1: launch_bal_wv<M, 1>(p); break;
         case 4: launch_bal_wv<M, 4>(p); break;
@@ -216,9 +221,14 @@ int main(int argc, char** argv)
     }
     if (getenv("BALBENCH_FUSED_ONLY")) return 0;
 
+    const bool only3 = getenv("BALBENCH_WPS3") != nullptr;
     for (int bpl : {2, 4, 8, 10}) {
         for (int wps : {2, 3, 4}) {
           for (int wv : {1, 4, 8}) {
+            if (only3) {   // bodies per lane 8 at three waves per SIMD (forced register budget) against two
+                if (bpl != 8 || wv != 4 || wps > 3) continue;
+                g_bal_wps3 = wps == 3;
+            } else
             if ((bpl == 10 && wps > 2) || (bpl == 8 && wps > 2) || (bpl == 2 && wps < 4) || (wps == 3 && wv == 1)) continue;
             nbk::BalLayout y{};
             if (!nbk::bal_plan(n, bpl, simds * wps, wv, &y)) continue;
