@@ -415,6 +415,11 @@ int nbody_plan(int n_targets, int n_sources, int kernel, int tile, int bodies_pe
 int nbody_plan_symmetric(int n, int num_cu, int waves, int bodies_per_lane, int* out_waves, int* out_bodies_per_lane,
                          int* out_blocks, int* out_workgroups);
 
+/* The fused small-N step's launch shape for n bodies on a chip of num_cu CUs, without a context or a device: targets per wave (2,
+ * or 4 when two would need more than 16 waves per workgroup), waves per workgroup (even, 2 ... 16), LDS tile in bodies, workgroups
+ * (one per CU up to 8192 bodies on 256 CUs). */
+int nbody_plan_fused(int n, int num_cu, int* out_targets_per_wave, int* out_waves, int* out_tile, int* out_workgroups);
+
 /* Waves per SIMD the library's cost estimates assume for the fp32 symmetric kernels with this many stationary bodies per
  * lane (2 at 10, 3 at 8, 5 at 4, 8 at 2): a property of the compiled kernels' register allocation, checked against the
  * compiler's own resource report by tests/test_build_resources.py. 0 for an unsupported count. */

@@ -132,6 +132,7 @@ _SIGNATURES = {
     "nbody_version": (C.c_char_p, []),
     "nbody_plan": (C.c_int, [C.c_int] * 7 + [C.POINTER(C.c_int)] * 4),
     "nbody_plan_symmetric": (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_int)] * 4),
+    "nbody_plan_fused": (C.c_int, [C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4),
     "nbody_plan_symmetric_occupancy": (C.c_int, [C.c_int]),
     "nbody_ctx_step_info": (C.c_int, [_p, C.c_int] + [C.POINTER(C.c_int)] * 4 + [C.POINTER(C.c_double)]),
     "nbody_ctx_step_info_f64": (C.c_int, [_p, C.c_int] + [C.POINTER(C.c_int)] * 4 + [C.POINTER(C.c_double)]),

@@ -1033,6 +1033,21 @@ int nbody_plan_symmetric(int n, int num_cu, int waves, int bodies_per_lane, int*
     return NBODY_OK;
 }
 
+// Device-free view of the fused step's launch shape (host tests).
+int nbody_plan_fused(int n, int num_cu, int* out_targets_per_wave, int* out_waves, int* out_tile, int* out_workgroups)
+{
+    if (n < 1 || num_cu <= 0) return fail(NBODY_ERR_INVALID, "bad plan arguments");
+    nbody_ctx tmp;
+    tmp.num_cu = num_cu;
+    FusedShape f{};
+    if (!fused_resolve(&tmp, n, &f)) return fail(NBODY_ERR_CONFIG, "no fused shape for %d bodies", n);
+    if (out_targets_per_wave) *out_targets_per_wave = f.T;
+    if (out_waves) *out_waves = f.wv;
+    if (out_tile) *out_tile = f.tile;
+    if (out_workgroups) *out_workgroups = f.grid;
+    return NBODY_OK;
+}
+
 int nbody_plan_symmetric_occupancy(int bodies_per_lane)
 {
     if (bodies_per_lane < 2 || bodies_per_lane > 16) return 0;

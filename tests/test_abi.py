@@ -176,3 +176,25 @@ def test_symmetric_shape_choice_without_a_device():
     assert plan(100)[0] != 0                                  # one block: nothing to pair up
     assert plan(262144, 3, 8)[0] != 0 and plan(-1)[0] != 0 and plan(1000, cus=0)[0] != 0
     assert plan(40_000_000)[0] != 0                           # beyond the 96 GiB slab cap: the one-sided kernel takes over
+
+
+def test_fused_step_shape_without_a_device(nb):
+    """nbody_plan_fused: the fused small-N step's launch shape. Every size gets a built instantiation (even wave counts 2 ... 16,
+    the tile each is compiled with), the grid covers all targets, and up to 8192 bodies on 256 CUs it is one workgroup per CU."""
+    lib = nb.load()
+    tiles = {2: 2048, 4: 2048, 6: 2304, 8: 2048, 10: 2560, 12: 2304, 14: 2688, 16: 2048}
+
+    def plan(n, cus=256):
+        o = [C.c_int() for _ in range(4)]
+        assert lib.nbody_plan_fused(n, cus, *[C.byref(x) for x in o]) == 0
+        return tuple(x.value for x in o)   # T, waves, tile, workgroups
+
+    assert plan(8192) == (2, 16, 2048, 256) and plan(4096) == (2, 8, 2048, 256) and plan(2048) == (2, 4, 2048, 256)
+    assert plan(6144) == (2, 12, 2304, 256) and plan(1024)[:2] == (2, 2) and plan(1) == (2, 2, 2048, 1)
+    for n in list(range(1, 300)) + list(range(300, 20000, 97)) + [8191, 8192, 8193, 10240, 16384, 65536]:
+        t, wv, tile, grid = plan(n)
+        assert t in (2, 4) and wv in tiles and tile == tiles[wv] and tile % (64 * wv) == 0
+        assert grid * wv * t >= n > (grid - 1) * wv * t
+        if n <= 8192:
+            assert t == 2 and grid <= 256
+    assert lib.nbody_plan_fused(0, 256, None, None, None, None) == nb._lib.ERR_INVALID
