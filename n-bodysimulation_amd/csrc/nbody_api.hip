@@ -1472,7 +1472,6 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
     FusedShape fs{};
     if (fused_wanted(c, n, &fs) && ensure_xalt(c, n) == NBODY_OK) {   // (no spare array to be had: the two-kernel paths below)
         // small systems: one launch per step (force + integrate), positions alternating between the caller's array and a spare one
-        const size_t bytes = (size_t)n * sizeof(float4);
         float4* const xa = reinterpret_cast<float4*>(d_bodies);
         float4* const xb = static_cast<float4*>(c->xalt);
         nbk::FusedParams fp{};
@@ -1486,7 +1485,10 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
             fp.xout = (k & 1) ? xa : xb;
             if (int rc = launch_fused(c, fs, fp, c->timing)) return rc;
         }
-        if (steps & 1) HIP_TRY(hipMemcpyAsync(xa, xb, bytes, hipMemcpyDeviceToDevice, c->stream));   // the result belongs in the caller's array
+        if (steps & 1) {   // the result belongs in the caller's array
+            nbk::copy_bodies<<<(n + 255) / 256, 256, 0, c->stream>>>(xa, xb, n);
+            HIP_TRY(hipGetLastError());
+        }
         return NBODY_OK;
     }
     SymShape y{};

@@ -1271,6 +1271,14 @@ struct FusedParams {
     float dt, eps2;
 };
 
+// dst[i] = src[i]: puts the positions of an odd step back into the caller's array (a launch on the same stream costs less than a
+// device-to-device hipMemcpyAsync of 128 KiB)
+__global__ void __launch_bounds__(256) copy_bodies(float4* __restrict__ dst, const float4* __restrict__ src, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
 template <int T, int WV, int TILE, int UNROLL = 8>
 __global__ void __launch_bounds__(64 * WV) step_fused(const FusedParams p)
 {
