@@ -168,6 +168,17 @@ int nbody_ctx_set_stream(nbody_ctx* ctx, void* hip_stream);
  * N=8192); the floor at small N is the dependent-kernel boundary, not the host. */
 int nbody_ctx_set_graph(nbody_ctx* ctx, int mode);
 
+/* Which decomposition runs a whole step of n bodies fastest depends on the chip and on the compiler; the switch-over sizes built
+ * into the library (fused step up to 8192 bodies, balanced runs to 45056, unit runs to 160000, block pairs above) were measured on
+ * MI355X with ROCm 7.2. nbody_ctx_autotune measures instead: it times `steps_per_trial` steps (three repeats, best taken) of every
+ * decomposition that applies to n bodies — on scratch copies of d_bodies with dt = 0, the caller's arrays are only read — and leaves
+ * the context's knobs (nbody_ctx_set_fused, nbody_ctx_set_symmetric_runs, bodies per lane) on the fastest. FAST kernel only.
+ * *out_choice: 1 fused step, 24 / 28 / 210 balanced runs with 4 / 8 / 10 bodies per lane, 3 unit runs, 4 what the library picks
+ * without any run-based variant (block pairs, or the two-kernel one-sided path at small sizes). Synchronous; costs a few hundred
+ * steps of the system. The knobs apply to every size the context is used with afterwards. */
+int nbody_ctx_autotune(nbody_ctx* ctx, const nbody_float4* d_bodies, int n, int steps_per_trial, int* out_choice,
+                       double* out_us_per_step);
+
 /* Pre-size the slab workspace for up to n_targets bodies so later calls never allocate. */
 int nbody_ctx_reserve(nbody_ctx* ctx, int n_targets);
 

@@ -1621,6 +1621,82 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
     return NBODY_OK;
 }
 
+// Measures the decompositions that apply to whole steps of n bodies on THIS device and leaves the context's knobs (fused step,
+// runs mode, bodies per lane) on the fastest: the switch-over sizes compiled into the library were measured on one pool of
+// MI355X boxes with one compiler; a different chip or ROCm release may move them.
+int nbody_ctx_autotune(nbody_ctx* c, const nbody_float4* d_bodies, int n, int steps_per_trial, int* out_choice, double* out_us_per_step)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (n < 1 || steps_per_trial < 1 || !d_bodies) return fail(NBODY_ERR_INVALID, "bad autotune arguments");
+    if (c->kernel != NBODY_KERNEL_FAST) return fail(NBODY_ERR_CONFIG, "autotune chooses among the FAST kernel's decompositions");
+    ON_DEVICE(c);
+    const size_t bytes = (size_t)n * sizeof(float4);
+    float4 *xs = nullptr, *vs = nullptr, *as = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&] {
+        if (xs) (void)hipFree(xs);
+        if (vs) (void)hipFree(vs);
+        if (as) (void)hipFree(as);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    };
+    if (hipMalloc(reinterpret_cast<void**>(&xs), bytes) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&vs), bytes) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&as), bytes) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        (void)hipGetLastError();
+        cleanup();
+        return fail(NBODY_ERR_NOMEM, "autotune: cannot allocate scratch state for %d bodies", n);
+    }
+    struct Knobs { int fused, sym_runs, sym_bpl, sym_waves; };
+    const Knobs saved{c->fused, c->sym_runs, c->sym_bpl, c->sym_waves};
+    const float saved_dt = c->dt;
+    const bool saved_timing = c->timing;
+    c->dt = 0.0f;          // the trial steps leave the scratch positions where they are
+    c->timing = false;
+    // choice id: 1 fused step, 2x balanced runs with x bodies per lane (24, 28, 210), 3 unit runs, 4 block pairs / two-kernel one-sided
+    struct Cand { int id; Knobs k; };
+    const Cand cands[] = {{1, {1, -1, 0, 0}}, {24, {0, 2, 4, 0}}, {28, {0, 2, 8, 0}}, {210, {0, 2, 10, 0}}, {3, {0, 1, 0, 0}}, {4, {0, 0, 0, 0}}};
+    int best = 0;
+    double best_us = 0.0;
+    Knobs best_k = saved;
+    int rc = NBODY_OK;
+    for (const Cand& cd : cands) {
+        if (cd.id == 1 && n > 65536) continue;                      // the one-sided fused step cannot win there; do not spend seconds on it
+        c->fused = cd.k.fused; c->sym_runs = cd.k.sym_runs; c->sym_bpl = cd.k.sym_bpl; c->sym_waves = cd.k.sym_waves;
+        int kind = 0;
+        if (nbody_ctx_step_info(c, n, &kind, nullptr, nullptr, nullptr, nullptr) != NBODY_OK) continue;
+        const int want = cd.id == 1 ? -1 : cd.id >= 24 ? 3 : cd.id == 3 ? 2 : kind;   // the decomposition the knobs were meant to select
+        if (kind != want || (cd.id == 4 && kind != 0 && kind != 1)) continue;          // does not apply at this size
+        if (hipMemcpyAsync(xs, d_bodies, bytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+            hipMemsetAsync(vs, 0, bytes, c->stream) != hipSuccess) { rc = fail(NBODY_ERR_HIP, "autotune: scratch setup failed"); break; }
+        rc = nbody_step(c, reinterpret_cast<nbody_float4*>(xs), reinterpret_cast<nbody_float4*>(as), reinterpret_cast<nbody_float4*>(vs), n, 4);   // warm-up, workspace
+        if (rc != NBODY_OK) { rc = NBODY_OK; continue; }           // this decomposition cannot run here (workspace): skip it
+        double us = 1e30;
+        for (int rep = 0; rep < 3 && rc == NBODY_OK; ++rep) {
+            (void)hipEventRecord(e0, c->stream);
+            rc = nbody_step(c, reinterpret_cast<nbody_float4*>(xs), reinterpret_cast<nbody_float4*>(as), reinterpret_cast<nbody_float4*>(vs), n, steps_per_trial);
+            (void)hipEventRecord(e1, c->stream);
+            if (hipEventSynchronize(e1) != hipSuccess) { rc = fail(NBODY_ERR_HIP, "autotune: trial failed"); break; }
+            float ms = 0.0f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            const double t = (double)ms * 1e3 / steps_per_trial;
+            if (t < us) us = t;
+        }
+        if (rc != NBODY_OK) break;
+        if (best == 0 || us < best_us) { best = cd.id; best_us = us; best_k = cd.k; }
+    }
+    c->dt = saved_dt;
+    c->timing = saved_timing;
+    const Knobs fin = (rc == NBODY_OK && best != 0) ? best_k : saved;
+    c->fused = fin.fused; c->sym_runs = fin.sym_runs; c->sym_bpl = fin.sym_bpl; c->sym_waves = fin.sym_waves;
+    (void)hipStreamSynchronize(c->stream);
+    cleanup();
+    if (rc != NBODY_OK) return rc;
+    if (best == 0) return fail(NBODY_ERR_CONFIG, "autotune: no decomposition ran for %d bodies", n);
+    if (out_choice) *out_choice = best;
+    if (out_us_per_step) *out_us_per_step = best_us;
+    return NBODY_OK;
+}
+
 int nbody_ctx_set_graph(nbody_ctx* c, int mode)
 {
     if (int rc = check_ctx(c)) return rc;

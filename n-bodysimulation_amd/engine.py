@@ -97,6 +97,14 @@ class Context:
         2 balanced (step-granular) runs always."""
         check(self._lib.nbody_ctx_set_symmetric_runs(self._h, mode))
 
+    def autotune(self, x: torch.Tensor, steps_per_trial: int = 50) -> dict:
+        """Times every decomposition that applies to whole steps of len(x) bodies on this device (scratch copies, dt = 0) and leaves
+        the context on the fastest. Returns {"choice": id, "us_per_step": t} (ids: nbody_ctx_autotune in nbody.h)."""
+        _check_f4(x)
+        choice, us = C.c_int(), C.c_double()
+        check(self._lib.nbody_ctx_autotune(self._h, _dptr(x), x.shape[0], steps_per_trial, C.byref(choice), C.byref(us)))
+        return {"choice": choice.value, "us_per_step": us.value}
+
     def set_fused(self, mode: int) -> None:
         """The fused small-N step (force + integrate in one launch): -1 where measurements prefer it, 0 never, 1 always (FAST)."""
         check(self._lib.nbody_ctx_set_fused(self._h, mode))

@@ -1146,3 +1146,25 @@ def test_fused_step_split_calls_and_the_simulate_boundary(nb, oracle):
     big.run(1)
     truth = oracle.accel_range(nb.engine.seeded_bodies(n2, 1, 4), 0, 512, 0, n2, eps2=0.002, f64acc=True)
     assert np.abs(big.state()[2][:512] - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 1e-5
+
+
+def test_autotune_measures_and_sets_the_knobs(nb, oracle):
+    """nbody_ctx_autotune: times the decompositions that apply to whole steps of n bodies on the device at hand (scratch copies,
+    dt = 0: the caller's array is only read) and leaves the context on the fastest. On MI355X that reproduces the built-in choice at
+    the sizes it was measured at; results afterwards stay within the fast tolerances whatever it picked."""
+    for n, expect in ((8192, (1,)), (16384, (24, 28, 210)), (2048, (1,))):
+        x0 = nb.engine.seeded_bodies(n, 1, 77)
+        sim = nb.engine.Simulation(x0, dt=0.01, eps2=0.002)
+        before = sim.x.clone()
+        r = sim.ctx.autotune(sim.x, steps_per_trial=40)
+        assert torch.equal(sim.x, before)                                   # the caller's bodies were only read
+        assert r["choice"] in expect, (n, r)
+        assert 1.0 < r["us_per_step"] < (35.0 if n <= 8192 else 90.0), (n, r)
+        info = sim.ctx.step_info(n)
+        assert info["fused"] == (r["choice"] == 1) and info["balanced"] == (r["choice"] >= 24)
+        sim.run(1)
+        truth = oracle.accel_range(x0, 0, 512, 0, n, eps2=0.002, f64acc=True)
+        assert np.abs(sim.state()[2][:512] - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 1e-5
+    ctx = nb.engine.Context(kernel=nb.KERNEL_STRICT)
+    with pytest.raises(nb.NBodyError):
+        ctx.autotune(torch.zeros((64, 4), device="cuda"))
