@@ -60,7 +60,7 @@ static bool read_file(const std::string& path, void* p, size_t bytes)
 
 int main(int argc, char** argv)
 {
-    int n = N_BODIES, steps = 10, kernel = NBODY_KERNEL_FAST, sync_each = 0, interactive = 0, json = 1, ngpu = 1, timeout_s = 900;
+    int n = N_BODIES, steps = 10, kernel = NBODY_KERNEL_FAST, sync_each = 0, interactive = 0, json = 1, ngpu = 1, timeout_s = 900, autotune = 0;
     bool f64 = false, force_shard = false;
     long steps_done = 0;
     float dt = DT, eps2 = EPS2;
@@ -87,10 +87,11 @@ int main(int argc, char** argv)
         else if (a == "--dump") dump = val();
         else if (a == "--load") load = val();
         else if (a == "--sync-each-step") sync_each = 1;
+        else if (a == "--autotune") autotune = 1;        // measure the decompositions on this device first (single GPU, fast kernel)
         else if (a == "--interactive") interactive = 1;
         else if (a == "--quiet") json = 0;
         else die("unknown option " + a + "\nusage: nbody_headless [--n N] [--steps K] [--dt f] [--eps2 f] [--init libc|ref|plummer] [--seed S]"
-                 " [--kernel fast|strict|onesided|symmetric] [--ngpu G] [--timeout S] [--shard] [--precision f32|f64] [--dump P] [--load P] [--sync-each-step]"
+                 " [--kernel fast|strict|onesided|symmetric] [--autotune] [--ngpu G] [--timeout S] [--shard] [--precision f32|f64] [--dump P] [--load P] [--sync-each-step]"
                  " [--interactive]");
     }
     if (interactive) {
@@ -295,6 +296,12 @@ int main(int argc, char** argv)
     ok(nbody_ctx_set_params(ctx, dt, eps2));
     ok(nbody_ctx_set_kernel(ctx, kernel, 0, 0, 0));
     ok(nbody_ctx_reserve(ctx, n));
+    if (autotune && kernel == NBODY_KERNEL_FAST && n > 0) {
+        int choice = 0;
+        double us = 0.0;
+        ok(nbody_ctx_autotune(ctx, (const nbody_float4*)d_bodies, n, 50, &choice, &us));
+        std::printf("autotune: decomposition %d, %.2f us per step\n", choice, us);
+    }
 
     std::printf("Starting the simulation...\n");         // main.cpp:145
     const auto t0 = std::chrono::steady_clock::now();
