@@ -160,8 +160,17 @@ def cpu_baseline(seconds_budget: float = 12.0):
         if time.perf_counter() - t0 > seconds_budget / 3:
             break
     dt2 = time.perf_counter() - t0
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     out.update({"port_all_cores_value": n * (n - 1) * reps / dt2, "port_all_cores": thr,
-                "host_cpus": os.cpu_count()})
+                "host_cpus": os.cpu_count(), "cpu_model": model})
     return out
 
 
