@@ -961,7 +961,9 @@ int nbody_ctx_set_workspace_limit(nbody_ctx* c, size_t bytes, int fail_above)
 int nbody_ctx_set_stream(nbody_ctx* c, void* hip_stream)
 {
     if (int rc = check_ctx(c)) return rc;
-    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    if (st != c->stream) c->ws_tag = 0;   // the inbox clear was ordered on the old stream: the next balanced launch clears again on the new one
+    c->stream = st;
     return NBODY_OK;
 }
 

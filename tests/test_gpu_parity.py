@@ -736,6 +736,49 @@ def test_config2_n65536_k10_prefix_against_oracle_subset(nb, oracle):
     assert np.isfinite(x10).all() and np.array_equal(x10[:, 3], x0[:, 3])
 
 
+def _energy_terms(x, v, eps2):
+    """Kinetic energy and softened potential energy of a state (torch fp64 on the GPU; test-side arithmetic only):
+    PE = -1/2 sum_{i != j} m_i m_j / sqrt(r_ij^2 + eps2), the potential of the pair force of kernel.cu:9-29."""
+    xd, vd = torch.from_numpy(x).cuda().double(), torch.from_numpy(v).cuda().double()
+    m = xd[:, 3]
+    ke = 0.5 * (m * (vd[:, :3] ** 2).sum(1)).sum().item()
+    pe = 0.0
+    for i0 in range(0, len(x), 2048):
+        d = xd[i0:i0 + 2048, None, :3] - xd[None, :, :3]
+        inv = torch.rsqrt((d * d).sum(2) + eps2)
+        pe -= 0.5 * ((m[i0:i0 + 2048, None] * m[None, :]) * inv).sum().item()
+        del d, inv
+    pe += 0.5 * (m * m).sum().item() / np.sqrt(eps2)        # the i == j terms counted above
+    return ke, pe
+
+
+def test_config2_full_run_1000_steps_conservation(nb, oracle):
+    """configs[1] in full: N=65536, dt=0.01, 1000 steps from a Plummer sphere — 4.3e12 interactions, out of the CPU checker's
+    reach, so the size-independent properties of the reference's own update rule (kernel.cu:116-129: v += 0.5*DT*a, x += DT*v
+    — symplectic Euler for H = KE + PE/2) carry the check: KE + PE/2 stays within its O(dt) oscillation instead of drifting,
+    total momentum stays at rounding level (every pair force is applied with both signs), masses are untouched, and a second
+    run from the same state is bit-identical."""
+    n, dt, eps2, steps = 65536, 0.01, 0.002, 1000
+    x0 = nb.engine.seeded_bodies(n, 1, 12345)
+    sim = nb.engine.Simulation(x0, dt=dt, eps2=eps2)
+    assert sim.ctx.step_info(n)["symmetric"]
+    ke0, pe0 = _energy_terms(x0, np.zeros_like(x0), eps2)
+    sim.run(steps)
+    x, v, a = sim.state()
+    assert np.isfinite(x).all() and np.isfinite(v).all() and np.array_equal(x[:, 3], x0[:, 3])
+    ke1, pe1 = _energy_terms(x, v, eps2)
+    h0, h1 = ke0 + 0.5 * pe0, ke1 + 0.5 * pe1
+    assert abs(h1 - h0) <= 2e-3 * abs(h0), (ke0, pe0, ke1, pe1)
+    assert ke1 > 0.05 * abs(pe0)                                  # the sphere did evolve: a cold start has fallen in
+    m = x0[:, 3:4].astype(np.float64)
+    p = (m * v[:, :3]).sum(0)
+    assert np.abs(p).max() <= 1e-7 * (m * np.abs(v[:, :3])).sum(), p     # measured 5e-9 (profiles/r03_energy_probe_n65536.txt)
+    sim2 = nb.engine.Simulation(x0, dt=dt, eps2=eps2)
+    sim2.run(steps)
+    for q, r in zip(sim2.state(), (x, v, a)):
+        assert np.array_equal(q, r)
+
+
 def test_config3_n262144_properties(nb, oracle):
     """configs[2]: N=262144 — sampled targets vs the CPU (1024 x 262144 pairs), momentum balance, exact
     mass linearity, and run-to-run bitwise reproducibility (fixed-order slab sums, no atomics)."""
@@ -868,6 +911,27 @@ def test_config4_size_n1048576_on_one_gpu(nb, oracle):
     assert np.abs(arn - ag[i0:i1])[:, :3].max() / np.abs(ag[:, :3]).max() <= 4e-5
     truth = oracle.accel_range(x0, i0, i0 + 256, 0, n, eps2=0.002, f64acc=True)
     assert np.abs(arn[:256] - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 2e-5
+
+
+def test_partial_sum_workspace_beyond_2p31_elements(nb, oracle):
+    """Maximum sizes: N = 2 400 000 (ragged: not a multiple of the 2560-body block) needs 938 slabs of N float4 = 2.25e9
+    partial-sum elements (36 GB) — past what a 32-bit element index reaches. One whole step: sampled bodies at both ends of
+    the array against the CPU over all sources, momentum balance, every output finite, masses untouched."""
+    n = 2400000
+    x0 = nb.engine.seeded_bodies(n, 1, 99)
+    sim = nb.engine.Simulation(x0, dt=0.01, eps2=0.002)
+    info = sim.ctx.step_info(n)
+    assert info["symmetric"] and not info["runs"] and info["slabs"] * n > 2 ** 31, info
+    sim.run(1)
+    x, v, a = sim.state()
+    assert np.isfinite(a).all() and np.isfinite(x).all() and np.array_equal(x[:, 3], x0[:, 3])
+    for i0 in (0, n - 128):
+        truth = oracle.accel_range(x0, i0, i0 + 128, 0, n, eps2=0.002, f64acc=True)
+        assert np.abs(a[i0:i0 + 128] - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 3e-5
+        vt = 0.5 * 0.01 * truth[:, :3]
+        assert np.abs(v[i0:i0 + 128, :3] - vt).max() / np.abs(vt).max() <= 3e-5
+    m = x0[:, 3:4].astype(np.float64)
+    assert np.abs((m * a[:, :3]).sum(0)).max() / (m * np.abs(a[:, :3])).sum() < 1e-6
 
 
 # ---- workspace cap and fallback (the symmetric kernels' O(N^2/B) partial-sum slabs) ---------------------------------
