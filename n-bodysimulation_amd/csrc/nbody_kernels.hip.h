@@ -1256,12 +1256,13 @@ __global__ void __launch_bounds__(64 * P) bal_reduce(const BalReduceParams p)
 // Below a few thousand bodies a step is not bound by arithmetic alone: every kernel boundary costs 1.5-2 us, every partial-sum
 // workspace has to be written by one launch and read back by the next. This kernel turns the one-sided evaluation round: a WAVE
 // owns T target bodies (held by every lane, packed two per register pair) and its 64 LANES split the sources — lane l takes
-// sources l, l + 64, ... of each LDS tile — so the complete sum of a target never leaves the wave: a butterfly over the lanes
-// (fixed order: reproducible) ends the force part, and lanes 0 .. T-1 integrate their target right there. N = 8192 with T = 4 is
-// 2048 waves, two per SIMD. Positions are read by every wave for the whole launch, so the advanced positions go to a SECOND array
-// (xout); the host alternates the two arrays from step to step (nbody_step keeps the spare one and copies back after an odd
-// number of steps). 12 packed ops + 2 v_rsq_f32 per two pairs, the one-sided count (33 cycles per 64 pairs): 15 us of VALU work
-// at N = 8192, against 25.7 us for force + partial sums + reduce in two launches.
+// sources l, l + 64, ... of each LDS tile — so the complete sum of a target never leaves the wave: four DPP row rotations and
+// four v_readlane (fixed order: reproducible) end the force part, and lanes 0 .. T-1 integrate their target right there. N = 8192
+// with T = 2 is 4096 waves, one workgroup of 16 per CU, four per SIMD. Positions are read by every wave for the whole launch, so
+// the advanced positions go to a SECOND array (xout); the host alternates the two arrays from step to step (nbody_step keeps the
+// spare one and copies back after an odd number of steps). 12 packed ops + 2 v_rsq_f32 per two pairs, the one-sided count (35
+// cycles per 64 pairs with the LDS reads): 16 us of VALU work at N = 8192 in a 20.5 us step, against 25.7 us for force + partial
+// sums + reduce in two launches.
 struct FusedParams {
     const float4* xin;   // positions at the start of the step
     float4* xout;        // advanced positions (another array: every wave reads xin until the end of the launch)
