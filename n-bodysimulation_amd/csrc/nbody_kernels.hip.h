@@ -1280,8 +1280,8 @@ __global__ void __launch_bounds__(256) copy_bodies(float4* __restrict__ dst, con
     if (i < n) dst[i] = src[i];
 }
 
-template <int T, int WV, int TILE, int UNROLL = 8>
-__global__ void __launch_bounds__(64 * WV) step_fused(const FusedParams p)
+template <int T, int WV, int TILE, int UNROLL = 8, int MINW = 1>
+__global__ void __launch_bounds__(64 * WV, MINW) step_fused(const FusedParams p)
 {
     static_assert(T % 2 == 0 && TILE % (64 * WV) == 0, "packed targets, whole loads per thread");
     constexpr int LPT = TILE / (64 * WV);

@@ -183,6 +183,11 @@ int main(int argc, char** argv)
 #define FUSEDU(T_, WV_, TILE_, U_) vars.push_back({"fused T" #T_ " wv" #WV_ " tile" #TILE_ " unroll" #U_, T_, WV_, TILE_, [&](const nbk::FusedParams& q) { \
             nbk::step_fused<T_, WV_, TILE_, U_><<<(n + T_ * WV_ - 1) / (T_ * WV_), 64 * WV_>>>(q); }})
             FUSEDU(2, 16, 2048, 2); FUSEDU(2, 16, 2048, 4); FUSEDU(2, 16, 2048, 8); FUSEDU(2, 16, 2048, 16); FUSEDU(2, 16, 1024, 4); FUSEDU(2, 16, 1024, 8); FUSEDU(2, 16, 2048, 4);
+        } else if (getenv("BALBENCH_FUSED_OCC")) {   // sizes above 8192: several workgroups per CU, registers capped so that they are co-resident
+#define FUSEDM(T_, WV_, TILE_, U_, M_) vars.push_back({"fused T" #T_ " wv" #WV_ " tile" #TILE_ " unroll" #U_ " minw" #M_, T_, WV_, TILE_, [&](const nbk::FusedParams& q) { \
+            nbk::step_fused<T_, WV_, TILE_, U_, M_><<<(n + T_ * WV_ - 1) / (T_ * WV_), 64 * WV_>>>(q); }})
+            FUSEDM(2, 10, 1280, 4, 5); FUSEDM(2, 10, 1280, 8, 5); FUSEDM(2, 10, 640, 4, 5); FUSEDM(2, 10, 2560, 4, 5); FUSEDM(2, 10, 1920, 4, 5);
+            FUSEDM(2, 8, 1024, 4, 6); FUSEDM(2, 12, 1536, 4, 6); FUSEDM(2, 12, 768, 4, 6); FUSEDM(2, 8, 2048, 4, 6); FUSEDM(2, 16, 2048, 4, 8); FUSEDM(2, 14, 1792, 4, 7);
         } else if (getenv("BALBENCH_FUSED_TWO_PER_CU")) {   // sizes above 8192: two workgroups per CU
             FUSED(2, 10, 1280); FUSED(2, 10, 2560); FUSED(2, 12, 1536); FUSED(2, 12, 2304); FUSED(2, 16, 2048); FUSED(2, 14, 1792); FUSED(2, 8, 2048); FUSED(4, 10, 2560);
             FUSED(4, 6, 2304); FUSED(4, 8, 2048);
