@@ -105,6 +105,10 @@ struct nbody_ctx {
     unsigned long long ws_tag = 0;     // which balanced-run layout the `slabs` workspace is cleared for (0 = none: any other user of it)
     bool ws_fail_above_limit = false;  // test hook: allocations above ws_limit are attempted and FAIL (out of memory) instead of
                                // being avoided by the shape choice
+    nbk::MassInfo* eqm = nullptr;  // two verdict slots of nbk::mass_scan: [0] square launches / whole steps, [1] cross launches
+    unsigned int eq_gen = 0;   // generation of the last scan
+    int eq_last_slot = 0;      // slot the last scan wrote
+    int eq_mode = -1;          // equal-mass path of the symmetric kernels: -1 / 1 where the device-side scan finds one common mass, 0 never
     void* xslabs = nullptr;    // workspace of nbody_accel_cross (its own, so that a square evaluation issued in parts
     size_t xslab_bytes = 0;    // around cross launches keeps its partial sums)
     bool legacy_eps = false;     // strict kernel evaluates `+ EPS2` as the older snapshot does
@@ -618,6 +622,40 @@ int ensure_inbox(nbody_ctx* c, const BalShape& b)
     return NBODY_OK;
 }
 
+// Equal-mass path: scans the bodies of the coming launch(es) on the stream (x[i0 .. i0+ni) and, when nj > 0, the run of nj bodies
+// from j0, wrapping at `wrap`) and hands out the verdict slot and this scan's generation. No host round trip: the force kernel
+// reads the verdict itself. *q stays nullptr when the path is switched off (or the verdict slots cannot be allocated).
+constexpr int kEqMinBodies = 4096;   // below this the scan launch costs more than the path saves
+
+int eq_scan(nbody_ctx* c, int slot, const float4* x, int i0, int ni, int j0, int nj, int wrap, const nbk::MassInfo** q, unsigned int* gen)
+{
+    *q = nullptr;
+    *gen = 0;
+    if (c->eq_mode == 0 || ni <= 0 || ni + nj < kEqMinBodies) return NBODY_OK;
+    if (!c->eqm) {
+        if (hipMalloc(reinterpret_cast<void**>(&c->eqm), 2 * sizeof(nbk::MassInfo)) != hipSuccess) {
+            (void)hipGetLastError();
+            c->eqm = nullptr;
+            return NBODY_OK;   // not an error of the step: the general path runs
+        }
+        HIP_TRY(hipMemset(c->eqm, 0, 2 * sizeof(nbk::MassInfo)));
+    }
+    if (++c->eq_gen == 0) ++c->eq_gen;   // 0 is what a fresh slot holds
+    nbk::MassScanParams mp{};
+    mp.x = x;
+    mp.i0 = i0; mp.ni = ni; mp.j0 = j0; mp.nj = nj; mp.wrap = wrap;
+    mp.out = c->eqm + slot;
+    mp.gen = c->eq_gen;
+    int blocks = (ni + nj + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    nbk::mass_scan<<<blocks, 256, 0, c->stream>>>(mp);
+    HIP_TRY(hipGetLastError());
+    c->eq_last_slot = slot;
+    *q = c->eqm + slot;
+    *gen = c->eq_gen;
+    return NBODY_OK;
+}
+
 template <class M, int TILE>
 void launch_lds(const nbk::ForceParams& p, dim3 grid, hipStream_t st)
 {
@@ -682,16 +720,13 @@ int launch_sym_untimed(nbody_ctx* c, const SymShape& y0, const nbk::SymParams& p
     y.grid = ntasks >= 0 ? ntasks : y0.grid - p.task0;
     if (y.grid <= 0) return NBODY_OK;
     const int key = y.waves * 100 + y.bpl;
-    // one range against itself, no wrap-around: the square-only build of the same kernel (the default large-N shapes; measured
-    // 1.5-2.7 % faster than the general one at N = 262144, profiles/r03_symbench_rows_262144.txt)
+    // one range against itself, no wrap-around: the square-only build of the same kernel (the default large-N shape; measured
+    // 1.5-2.7 % faster than the general one at N = 262144, profiles/r03_symbench_rows_262144.txt). Only for 10 bodies per lane: with
+    // the equal-mass path compiled in, the square build for 8 needs 178 VGPRs (two waves per SIMD instead of three); the general
+    // kernel keeps 164.
     const bool square = !p.rect && !p.wrap && p.i0 == p.j0 && p.ni == p.nj && p.slabs_i == p.slabs_j;
     if (square && key == 410) {
         nbk::force_sym_square<SymPacked<10>, 4><<<y.grid, 256, 0, c->stream>>>(p);
-        HIP_TRY(hipGetLastError());
-        return NBODY_OK;
-    }
-    if (square && key == 408) {
-        nbk::force_sym_square<SymPacked<8>, 4><<<y.grid, 256, 0, c->stream>>>(p);
         HIP_TRY(hipGetLastError());
         return NBODY_OK;
     }
@@ -861,6 +896,7 @@ int nbody_ctx_destroy(nbody_ctx* c)
     if (c->slabs) (void)hipFree(c->slabs);
     if (c->xslabs) (void)hipFree(c->xslabs);
     if (c->xalt) (void)hipFree(c->xalt);
+    if (c->eqm) (void)hipFree(c->eqm);
     if (c->legacy_buf) (void)hipFree(c->legacy_buf);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -945,6 +981,34 @@ int nbody_ctx_set_fused(nbody_ctx* c, int mode)
     if (int rc = check_ctx(c)) return rc;
     if (mode < -1 || mode > 1) return fail(NBODY_ERR_CONFIG, "fused mode must be -1 (auto), 0 (never) or 1 (always)");
     c->fused = mode;
+    return NBODY_OK;
+}
+
+int nbody_ctx_set_equal_mass(nbody_ctx* c, int mode)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (mode < -1 || mode > 1) return fail(NBODY_ERR_CONFIG, "equal-mass mode must be -1 (auto), 0 (never) or 1 (wherever the scan finds one common mass)");
+    c->eq_mode = mode;
+    return NBODY_OK;
+}
+
+int nbody_ctx_equal_mass_verdict(nbody_ctx* c, int* scanned, int* uniform, float* mass)
+{
+    if (int rc = check_ctx(c)) return rc;
+    ON_DEVICE(c);
+    if (scanned) *scanned = 0;
+    if (uniform) *uniform = 0;
+    if (mass) *mass = 0.0f;
+    if (!c->eqm || c->eq_gen == 0) return NBODY_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    nbk::MassInfo h[2];
+    HIP_TRY(hipMemcpy(h, c->eqm, sizeof h, hipMemcpyDeviceToHost));
+    // the most recent scan (either slot) carries the context's current generation unless it found the bodies uniform: a slot
+    // whose stamp is the current generation is the latest scan and says "not uniform"
+    const bool bad = h[0].bad_gen == c->eq_gen || h[1].bad_gen == c->eq_gen;
+    if (scanned) *scanned = 1;
+    if (uniform) *uniform = bad ? 0 : 1;
+    if (mass) *mass = h[c->eq_last_slot].m0;
     return NBODY_OK;
 }
 
@@ -1208,6 +1272,7 @@ int accel_impl(nbody_ctx* c, const nbody_float4* d_bodies, nbody_float4* d_acc_o
             bp.n = nt;
             bp.y = by.y;
             bp.eps2 = c->eps2;
+            if (int rc2 = eq_scan(c, 0, reinterpret_cast<const float4*>(d_bodies), i0, nt, 0, 0, 0, &bp.eqm, &bp.eq_gen)) return rc2;
             if (int rc2 = launch_bal(c, bp, true)) return rc2;
             nbk::BalReduceParams rp{};
             rp.inbox = static_cast<const float4*>(c->slabs);
@@ -1234,6 +1299,7 @@ int accel_impl(nbody_ctx* c, const nbody_float4* d_bodies, nbody_float4* d_acc_o
         if (int rc = ensure_slabs(c, (size_t)ry.max_slabs * nt * sizeof(float4))) return rc;
         nbk::RunParams rp{};
         run_params(&rp, reinterpret_cast<const float4*>(d_bodies) + i0, nt, ry, static_cast<float4*>(c->slabs), c->eps2);
+        if (int rc = eq_scan(c, 0, reinterpret_cast<const float4*>(d_bodies), i0, nt, 0, 0, 0, &rp.eqm, &rp.eq_gen)) return rc;
         if (int rc = launch_run(c, ry, rp)) return rc;
         nbk::ReduceParams r{};
         r.out = reinterpret_cast<float4*>(d_acc_out);
@@ -1253,6 +1319,7 @@ int accel_impl(nbody_ctx* c, const nbody_float4* d_bodies, nbody_float4* d_acc_o
         if (int rc = ensure_slabs(c, (size_t)y.nb * nt * sizeof(float4))) return rc;
         nbk::SymParams sp{};
         sym_square_params(&sp, reinterpret_cast<const float4*>(d_bodies), i0, nt, y, static_cast<float4*>(c->slabs), c->eps2);
+        if (int rc = eq_scan(c, 0, sp.x, i0, nt, 0, 0, 0, &sp.eqm, &sp.eq_gen)) return rc;
         if (int rc = launch_sym(c, y, sp)) return rc;
         nbk::ReduceParams r{};
         r.out = reinterpret_cast<float4*>(d_acc_out);
@@ -1335,6 +1402,7 @@ int nbody_accel_square_part(nbody_ctx* c, const nbody_float4* d_bodies, nbody_fl
     if (int rc = ensure_slabs(c, (size_t)y.nb * nt * sizeof(float4))) return rc;
     nbk::SymParams sp{};
     sym_square_params(&sp, reinterpret_cast<const float4*>(d_bodies), i0, nt, y, static_cast<float4*>(c->slabs), c->eps2);
+    if (int rc = eq_scan(c, 0, sp.x, i0, nt, 0, 0, 0, &sp.eqm, &sp.eq_gen)) return rc;   // every part asks again (a few microseconds; other launches may lie between the parts)
     const long t0 = (long)y.grid * part / nparts, t1 = (long)y.grid * (part + 1) / nparts;
     sp.task0 = (int)t0;
     if (int rc = launch_sym(c, y, sp, (int)(t1 - t0))) return rc;
@@ -1418,6 +1486,7 @@ int nbody_accel_cross(nbody_ctx* c, const nbody_float4* d_bodies, int n_total, n
         sp.stride_i = ni; sp.stride_j = cnt;
         sp.rect = 1;
         sp.eps2 = c->eps2;
+        if (int rc = eq_scan(c, 1, sp.x, i0, ni, sp.j0, cnt, n_total, &sp.eqm, &sp.eq_gen)) return rc;
         if (int rc = launch_sym(c, y, sp)) return rc;
         nbk::ReduceParams r{};
         r.out = reinterpret_cast<float4*>(d_acc_i);
@@ -1569,6 +1638,18 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
             q.slab_stride = n;
         }
     }
+    const bool graphable = !c->timing && (c->use_graph == 1 || (c->use_graph < 0 && n <= kGraphMaxN));
+    // equal-mass path of the symmetric kernels: one scan per call (the integrate carries the masses through unchanged). Not under
+    // graph capture (the generation number would be frozen into the graph). Same size rule as nbody_accel_range, so that a step
+    // and the accel + integrate pair it is made of keep giving the same bits.
+    if ((bal || runs || sym) && !(graphable && steps >= kGraphChunk)) {
+        const nbk::MassInfo* q = nullptr;
+        unsigned int gen = 0;
+        if (int rc = eq_scan(c, 0, reinterpret_cast<const float4*>(d_bodies), 0, n, 0, 0, 0, &q, &gen)) return rc;
+        bp.eqm = q; bp.eq_gen = gen;
+        rp.eqm = q; rp.eq_gen = gen;
+        sp.eqm = q; sp.eq_gen = gen;
+    }
     const int iblocks = (n + nbk::kWG - 1) / nbk::kWG;
     // one step = one force launch + one integrate launch, both checked
     auto enqueue_step = [&](bool timed) -> int {
@@ -1586,7 +1667,6 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
         return NBODY_OK;
     };
     int k = 0;
-    const bool graphable = !c->timing && (c->use_graph == 1 || (c->use_graph < 0 && n <= kGraphMaxN));
     if (graphable && steps >= kGraphChunk) {
         // Launch-bound regime: replay a captured chain of kGraphChunk steps instead of 2*kGraphChunk
         // host launches. The kernels and their order are exactly those of the loop below.

@@ -303,6 +303,63 @@ __global__ void __launch_bounds__(kWG, MINW) force_sgpr(const ForceParams p)
 // slab element is written exactly once per launch and the integrate kernel adds the nb slabs in
 // index order: deterministic, no float atomics.
 
+// EQUAL-MASS systems (a Plummer model, most cosmological and cluster initial conditions: m_i = M / N). When every body a launch
+// touches has bit-for-bit the same mass m0, a_i = m0 * sum_j w_ij r_ij: the symmetric kernels then accumulate sum w r on both sides
+// — no m_j w, no m_i w, no mass to rotate: 89 instead of 100 VALU instructions per rotation step — and apply m0 once per stored sum.
+// mass_scan decides on the device, in stream order (no host round trip): it compares every body of the launch's ranges with the
+// first one and stamps `bad_gen` with the launch's generation number when one differs (or a coordinate is beyond kEqMaxCoord or
+// not finite, see the padding below); the force kernel takes the equal-mass path when the stamp is not its own generation.
+// Padding bodies (past the end of a range) have no mass to switch them off on that path: they sit at (1e18, 1e18, 1e18), where
+// w = rsq(d)^3 underflows to exactly 0 against every body within kEqMaxCoord of the origin.
+struct MassInfo {
+    unsigned int bad_gen;   // generation of the last scan that found the bodies NOT uniform
+    float m0;               // mass of the first body of the last scan
+};
+constexpr float kEqMaxCoord = 1e15f;
+constexpr float kEqFar = 1e18f;
+
+struct MassScanParams {
+    const float4* x;
+    int i0, ni;      // first range
+    int j0, nj;      // second range (nj = 0: none); indices at or beyond `wrap` continue at body 0 when wrap > 0
+    int wrap;
+    MassInfo* out;
+    unsigned int gen;
+};
+
+__global__ void __launch_bounds__(256) mass_scan(const MassScanParams p)
+{
+    const unsigned int ref = __builtin_bit_cast(unsigned int, p.x[p.i0].w);
+    bool bad = false;
+    const int total = p.ni + p.nj;
+    for (int e = (int)blockIdx.x * 256 + (int)threadIdx.x; e < total; e += (int)gridDim.x * 256) {
+        int idx;
+        if (e < p.ni) idx = p.i0 + e;
+        else {
+            idx = p.j0 + (e - p.ni);
+            if (p.wrap && idx >= p.wrap) idx -= p.wrap;
+        }
+        const float4 b = p.x[idx];
+        bad |= __builtin_bit_cast(unsigned int, b.w) != ref;
+        bad |= !(__builtin_fabsf(b.x) <= kEqMaxCoord && __builtin_fabsf(b.y) <= kEqMaxCoord && __builtin_fabsf(b.z) <= kEqMaxCoord);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const float m0 = __builtin_bit_cast(float, ref);
+        p.out->m0 = m0;
+        bad |= !(__builtin_fabsf(m0) <= 3.0e38f);   // a NaN or infinite common mass: the general path reproduces it term by term
+    }
+    if (bad) p.out->bad_gen = p.gen;   // every writer stores the same value
+}
+
+// the launch's verdict: wave-uniform (scalar loads from a kernel-argument pointer)
+__device__ __forceinline__ bool eq_uniform(const MassInfo* q, const unsigned int gen, float* m0)
+{
+    if (!q) return false;
+    const unsigned int bad = __builtin_amdgcn_readfirstlane((int)q->bad_gen);
+    *m0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, q->m0)));
+    return bad != gen;
+}
+
 template <class V4, class S>
 struct SymParamsT {
     const V4* x;          // bodies {x,y,z,mass}, indexed absolutely
@@ -318,6 +375,8 @@ struct SymParamsT {
                           //    (nbi == nbj == nb, slabs_i == slabs_j: slab J gets the I-side sums, slab I the J-side sums)
                           // 1: TWO disjoint ranges: every (I, J) block pair, symmetric; slab J of slabs_i, slab I of slabs_j
     S eps2;
+    const MassInfo* eqm;  // mass_scan's verdict on this launch's ranges (nullptr: general path)
+    unsigned int eq_gen;  // this launch's generation
 };
 using SymParams = SymParamsT<float4, float>;
 using SymParamsF64 = SymParamsT<double4, double>;
@@ -350,6 +409,14 @@ __device__ __forceinline__ double ror(const double v)
 template <class V4> __device__ __forceinline__ V4 zero4();
 template <> __device__ __forceinline__ float4 zero4<float4>() { return make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
 template <> __device__ __forceinline__ double4 zero4<double4>() { return make_double4(0.0, 0.0, 0.0, 0.0); }
+// a body past the end of its range: massless at the origin (adds exactly +-0 to every real body); on the equal-mass path, where
+// no mass switches it off, far away instead (w underflows to exactly 0)
+template <class V4, bool EQ> __device__ __forceinline__ V4 pad4()
+{
+    V4 v = zero4<V4>();
+    if (EQ) { v.x = kEqFar; v.y = kEqFar; v.z = kEqFar; }
+    return v;
+}
 
 // Packed arithmetic for the rotation kernel: BPL stationary bodies per lane, two per register pair.
 template <int BPL_>
@@ -377,8 +444,18 @@ struct SymPacked {
     {
         return make_float4(ax[k >> 1][k & 1], ay[k >> 1][k & 1], az[k >> 1][k & 1], 0.0f);
     }
-    // all BPL stationary bodies against the moving body s; t = sum_k (m_k w_k) r_k when SYM
-    template <bool SYM>
+    // the sums so far times s (the equal-mass path accumulates sum w r and applies the common mass once, at the end)
+    __device__ __forceinline__ void scale(const float s)
+    {
+        const f32x2 v = {s, s};
+#pragma unroll
+        for (int k = 0; k < H; ++k) { ax[k] = ax[k] * v; ay[k] = ay[k] * v; az[k] = az[k] * v; }
+    }
+    // all BPL stationary bodies against the moving body s; t = sum_k (m_k w_k) r_k when SYM.
+    // EQ: every body of the launch has the same mass (MassInfo below): a_i += w r, t += w r — the two mass multiplies per pair
+    // (and the moving body's mass itself) drop out, the common mass is applied once per stored sum. 14 instead of 16 packed ops
+    // per two pair evaluations.
+    template <bool SYM, bool EQ = false>
     __device__ __forceinline__ void pairs(const float sx, const float sy, const float sz, const float sm, float& tx,
                                           float& ty, float& tz)
     {
@@ -402,7 +479,7 @@ struct SymPacked {
 #pragma unroll
         for (int k = 0; k < H; ++k) w[k] = d[k] * w[k];
 #pragma unroll
-        for (int k = 0; k < H; ++k) fi[k] = bm * w[k];
+        for (int k = 0; k < H; ++k) fi[k] = EQ ? w[k] : bm * w[k];
 #pragma unroll
         for (int k = 0; k < H; ++k) {
             ax[k] = __builtin_elementwise_fma(rx[k], fi[k], ax[k]);
@@ -410,8 +487,10 @@ struct SymPacked {
             az[k] = __builtin_elementwise_fma(rz[k], fi[k], az[k]);
         }
         if (SYM) {
+            if (!EQ) {
 #pragma unroll
-            for (int k = 0; k < H; ++k) fi[k] = m[k] * w[k];
+                for (int k = 0; k < H; ++k) fi[k] = m[k] * w[k];
+            }
             ux = rx[0] * fi[0]; uy = ry[0] * fi[0]; uz = rz[0] * fi[0];
 #pragma unroll
             for (int k = 1; k < H; ++k) {
@@ -445,7 +524,12 @@ struct SymScalar {
         ax[k] = 0.0f; ay[k] = 0.0f; az[k] = 0.0f;
     }
     __device__ __forceinline__ float4 acc(int k) const { return make_float4(ax[k], ay[k], az[k], 0.0f); }
-    template <bool SYM>
+    __device__ __forceinline__ void scale(const float s)
+    {
+#pragma unroll
+        for (int k = 0; k < BPL; ++k) { ax[k] *= s; ay[k] *= s; az[k] *= s; }
+    }
+    template <bool SYM, bool EQ = false>
     __device__ __forceinline__ void pairs(const float sx, const float sy, const float sz, const float sm, float& tx,
                                           float& ty, float& tz)
     {
@@ -460,12 +544,12 @@ struct SymScalar {
             d = __builtin_fmaf(rz, rz, d);
             const float inv = __builtin_amdgcn_rsqf(d);
             const float w = inv * inv * inv;
-            const float fi = sm * w;
+            const float fi = EQ ? w : sm * w;
             ax[k] = __builtin_fmaf(rx, fi, ax[k]);
             ay[k] = __builtin_fmaf(ry, fi, ay[k]);
             az[k] = __builtin_fmaf(rz, fi, az[k]);
             if (SYM) {
-                const float fj = m[k] * w;
+                const float fj = EQ ? w : m[k] * w;
                 if (k == 0) { tx = rx * fj; ty = ry * fj; tz = rz * fj; }
                 else {
                     tx = __builtin_fmaf(rx, fj, tx);
@@ -498,7 +582,12 @@ struct SymF64 {
         ax[k] = 0.0; ay[k] = 0.0; az[k] = 0.0;
     }
     __device__ __forceinline__ double4 acc(int k) const { return make_double4(ax[k], ay[k], az[k], 0.0); }
-    template <bool SYM>
+    __device__ __forceinline__ void scale(const double s)
+    {
+#pragma unroll
+        for (int k = 0; k < BPL; ++k) { ax[k] *= s; ay[k] *= s; az[k] *= s; }
+    }
+    template <bool SYM, bool EQ = false>
     __device__ __forceinline__ void pairs(const double sx, const double sy, const double sz, const double sm, double& tx,
                                           double& ty, double& tz)
     {
@@ -516,12 +605,12 @@ struct SymF64 {
         }
 #pragma unroll
         for (int k = 0; k < BPL; ++k) {
-            const double fi = sm * w[k];
+            const double fi = EQ ? w[k] : sm * w[k];
             ax[k] = __builtin_fma(rx[k], fi, ax[k]);
             ay[k] = __builtin_fma(ry[k], fi, ay[k]);
             az[k] = __builtin_fma(rz[k], fi, az[k]);
             if (SYM) {
-                const double fj = m[k] * w[k];
+                const double fj = EQ ? w[k] : m[k] * w[k];
                 tx = __builtin_fma(rx[k], fj, tx);
                 ty = __builtin_fma(ry[k], fj, ty);
                 tz = __builtin_fma(rz[k], fj, tz);
@@ -530,11 +619,12 @@ struct SymF64 {
     }
 };
 
-template <int S, bool SYM, class M>
+template <int S, bool SYM, bool EQ = false, class M>
 __device__ __forceinline__ void sym_step(M& t, const typename M::V4& bj, typename M::V4& aj)
 {
     typename M::S tx, ty, tz;
-    t.template pairs<SYM>(ror<S>(bj.x), ror<S>(bj.y), ror<S>(bj.z), ror<S>(bj.w), tx, ty, tz);
+    if constexpr (EQ) t.template pairs<SYM, true>(ror<S>(bj.x), ror<S>(bj.y), ror<S>(bj.z), typename M::S(0), tx, ty, tz);   // no mass to rotate
+    else t.template pairs<SYM, false>(ror<S>(bj.x), ror<S>(bj.y), ror<S>(bj.z), ror<S>(bj.w), tx, ty, tz);
     if (SYM) {  // a_j = -sum_i (m_i w) r, delivered to the moving body's lane
         aj.x -= ror<(16 - S) % 16>(tx);
         aj.y -= ror<(16 - S) % 16>(ty);
@@ -542,13 +632,13 @@ __device__ __forceinline__ void sym_step(M& t, const typename M::V4& bj, typenam
     }
 }
 
-template <bool SYM, class M>
+template <bool SYM, bool EQ = false, class M>
 __device__ __forceinline__ void sym_row_pass(M& t, const typename M::V4& bj, typename M::V4& aj)
 {
-    sym_step<0, SYM>(t, bj, aj);  sym_step<1, SYM>(t, bj, aj);  sym_step<2, SYM>(t, bj, aj);  sym_step<3, SYM>(t, bj, aj);
-    sym_step<4, SYM>(t, bj, aj);  sym_step<5, SYM>(t, bj, aj);  sym_step<6, SYM>(t, bj, aj);  sym_step<7, SYM>(t, bj, aj);
-    sym_step<8, SYM>(t, bj, aj);  sym_step<9, SYM>(t, bj, aj);  sym_step<10, SYM>(t, bj, aj); sym_step<11, SYM>(t, bj, aj);
-    sym_step<12, SYM>(t, bj, aj); sym_step<13, SYM>(t, bj, aj); sym_step<14, SYM>(t, bj, aj); sym_step<15, SYM>(t, bj, aj);
+    sym_step<0, SYM, EQ>(t, bj, aj);  sym_step<1, SYM, EQ>(t, bj, aj);  sym_step<2, SYM, EQ>(t, bj, aj);  sym_step<3, SYM, EQ>(t, bj, aj);
+    sym_step<4, SYM, EQ>(t, bj, aj);  sym_step<5, SYM, EQ>(t, bj, aj);  sym_step<6, SYM, EQ>(t, bj, aj);  sym_step<7, SYM, EQ>(t, bj, aj);
+    sym_step<8, SYM, EQ>(t, bj, aj);  sym_step<9, SYM, EQ>(t, bj, aj);  sym_step<10, SYM, EQ>(t, bj, aj); sym_step<11, SYM, EQ>(t, bj, aj);
+    sym_step<12, SYM, EQ>(t, bj, aj); sym_step<13, SYM, EQ>(t, bj, aj); sym_step<14, SYM, EQ>(t, bj, aj); sym_step<15, SYM, EQ>(t, bj, aj);
 }
 
 __device__ __forceinline__ float next_row(const float v, const int addr)
@@ -567,15 +657,15 @@ __device__ __forceinline__ double next_row(const double v, const int addr)
 __device__ __forceinline__ int sym_row_offset(int I, int nb) { return (int)(((long)I * (2L * nb - I - 1)) / 2); }
 
 // block = 64*W threads. rect == 0: grid = nb*(nb-1)/2 pair tasks followed by nb diagonal tasks;
-// rect == 1: grid = nbi*nbj pair tasks.
-template <class M, int W>
-__device__ __forceinline__ void force_sym_body(const SymParamsT<typename M::V4, typename M::S>& p)
+// rect == 1: grid = nbi*nbj pair tasks. EQ: the equal-mass path (m0 = the common mass).
+template <class M, int W, bool EQ>
+__device__ __forceinline__ void force_sym_body_t(const SymParamsT<typename M::V4, typename M::S>& p, typename M::V4* const sh,
+                                                 const typename M::S m0)
 {
     constexpr int BPL = M::BPL;
     constexpr int B = 64 * W * BPL;
     constexpr int NCH = B / 64;
     using V4 = typename M::V4;
-    __shared__ V4 sh[B];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -602,15 +692,14 @@ __device__ __forceinline__ void force_sym_body(const SymParamsT<typename M::V4, 
         }
     }
 
-    // a body past the end of its range is replaced by a massless one at the origin: it adds exactly
-    // +-0 to every real body, and what it collects itself is never stored
+    // a body past the end of its range adds exactly +-0 to every real body (pad4), and what it collects itself is never stored
     M t;
     t.set_eps2(p.eps2);
     const int ibase = I * B + w * (64 * BPL) + lane;  // index within the I range
 #pragma unroll
     for (int k = 0; k < BPL; ++k) {
         const int i = ibase + k * 64;
-        t.set(k, i < p.ni ? p.x[p.i0 + i] : zero4<V4>());
+        t.set(k, i < p.ni ? p.x[p.i0 + i] : pad4<V4, EQ>());
     }
     const int jbase = J * B + lane;  // index within the J run
     const int rot = ((lane + 16) & 63) << 2;
@@ -619,7 +708,7 @@ __device__ __forceinline__ void force_sym_body(const SymParamsT<typename M::V4, 
         const int j = jbase + c * 64;
         int ja = p.j0 + j;
         if (p.wrap && ja >= p.wrap) ja -= p.wrap;
-        return j < p.nj ? p.x[ja] : zero4<V4>();
+        return j < p.nj ? p.x[ja] : pad4<V4, EQ>();
     };
 
     if (!diag) {
@@ -636,14 +725,16 @@ __device__ __forceinline__ void force_sym_body(const SymParamsT<typename M::V4, 
         if (diag) {
             V4 aj = zero4<V4>();
             for (int ph = 0; ph < 4; ++ph) {
-                sym_row_pass<false>(t, bj, aj);
-                bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot); bj.w = next_row(bj.w, rot);
+                sym_row_pass<false, EQ>(t, bj, aj);
+                bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot);
+                if (!EQ) bj.w = next_row(bj.w, rot);
             }
         } else {
             V4 aj = sh[c * 64 + lane];
             for (int ph = 0; ph < 4; ++ph) {
-                sym_row_pass<true>(t, bj, aj);
-                bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot); bj.w = next_row(bj.w, rot);
+                sym_row_pass<true, EQ>(t, bj, aj);
+                bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot);
+                if (!EQ) bj.w = next_row(bj.w, rot);
                 aj.x = next_row(aj.x, rot); aj.y = next_row(aj.y, rot); aj.z = next_row(aj.z, rot);
             }
             sh[c * 64 + lane] = aj;
@@ -652,6 +743,7 @@ __device__ __forceinline__ void force_sym_body(const SymParamsT<typename M::V4, 
         c = cn;
     }
 
+    if (EQ) t.scale(m0);
     V4* const out_i = p.slabs_i + (size_t)J * p.stride_i;
 #pragma unroll
     for (int k = 0; k < BPL; ++k) {
@@ -664,11 +756,21 @@ __device__ __forceinline__ void force_sym_body(const SymParamsT<typename M::V4, 
             const int j = J * B + e;
             if (j < p.nj) {
                 V4 a = sh[e];
+                if (EQ) { a.x *= m0; a.y *= m0; a.z *= m0; }
                 a.w = 0;
                 out_j[j] = a;
             }
         }
     }
+}
+
+template <class M, int W>
+__device__ __forceinline__ void force_sym_body(const SymParamsT<typename M::V4, typename M::S>& p)
+{
+    __shared__ typename M::V4 sh[64 * W * M::BPL];
+    float m0 = 0.0f;
+    if (eq_uniform(p.eqm, p.eq_gen, &m0)) force_sym_body_t<M, W, true>(p, sh, (typename M::S)m0);
+    else force_sym_body_t<M, W, false>(p, sh, (typename M::S)m0);
 }
 
 template <class M, int W, int MINW = 1>
@@ -681,14 +783,14 @@ __global__ void __launch_bounds__(64 * W, MINW) force_sym(const SymParamsT<typen
 // slab layout as force_sym, without the run-time rectangle / wrap-around handling. Measured 2.7 % faster than the general kernel at
 // N = 262144 (tools/symbench.hip, profiles/r03_symbench_rows.txt: 10.98 vs 11.29 ms per launch on one box) — the instruction
 // schedule of the rotation pass that hipcc finds for the simpler control flow, not a different algorithm.
-template <class M, int W>
-__global__ void __launch_bounds__(64 * W, 1) force_sym_square(const SymParamsT<typename M::V4, typename M::S> p)
+template <class M, int W, bool EQ>
+__device__ __forceinline__ void force_sym_square_t(const SymParamsT<typename M::V4, typename M::S>& p, typename M::V4* const sh,
+                                                   const typename M::S m0)
 {
     constexpr int BPL = M::BPL;
     constexpr int B = 64 * W * BPL;
     constexpr int NCH = B / 64;
     using V4 = typename M::V4;
-    __shared__ V4 sh[B];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nb = p.nbi;
@@ -715,13 +817,13 @@ __global__ void __launch_bounds__(64 * W, 1) force_sym_square(const SymParamsT<t
 #pragma unroll
     for (int k = 0; k < BPL; ++k) {
         const int i = ibase + k * 64;
-        t.set(k, i < n ? x[i] : zero4<V4>());
+        t.set(k, i < n ? x[i] : pad4<V4, EQ>());
     }
     const int rot = ((lane + 16) & 63) << 2;
     const int jbase = J * B + lane;
     auto fetch = [&](int c) {
         const int j = jbase + c * 64;
-        return j < n ? x[j] : zero4<V4>();
+        return j < n ? x[j] : pad4<V4, EQ>();
     };
     if (!diag) {
 #pragma unroll
@@ -737,14 +839,16 @@ __global__ void __launch_bounds__(64 * W, 1) force_sym_square(const SymParamsT<t
         if (diag) {
             V4 aj = zero4<V4>();
             for (int ph = 0; ph < 4; ++ph) {
-                sym_row_pass<false>(t, bj, aj);
-                bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot); bj.w = next_row(bj.w, rot);
+                sym_row_pass<false, EQ>(t, bj, aj);
+                bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot);
+                if (!EQ) bj.w = next_row(bj.w, rot);
             }
         } else {
             V4 aj = sh[c * 64 + lane];
             for (int ph = 0; ph < 4; ++ph) {
-                sym_row_pass<true>(t, bj, aj);
-                bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot); bj.w = next_row(bj.w, rot);
+                sym_row_pass<true, EQ>(t, bj, aj);
+                bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot);
+                if (!EQ) bj.w = next_row(bj.w, rot);
                 aj.x = next_row(aj.x, rot); aj.y = next_row(aj.y, rot); aj.z = next_row(aj.z, rot);
             }
             sh[c * 64 + lane] = aj;
@@ -756,15 +860,30 @@ __global__ void __launch_bounds__(64 * W, 1) force_sym_square(const SymParamsT<t
         V4* const out_j = p.slabs_j + (size_t)I * p.stride_j;
         for (int e = tid; e < B; e += 64 * W) {
             const int j = J * B + e;
-            if (j < n) { V4 a = sh[e]; a.w = 0; out_j[j] = a; }
+            if (j < n) {
+                V4 a = sh[e];
+                if (EQ) { a.x *= m0; a.y *= m0; a.z *= m0; }
+                a.w = 0;
+                out_j[j] = a;
+            }
         }
     }
+    if (EQ) t.scale(m0);
     V4* const out_i = p.slabs_i + (size_t)J * p.stride_i;
 #pragma unroll
     for (int k = 0; k < BPL; ++k) {
         const int i = ibase + k * 64;
         if (i < n) out_i[i] = t.acc(k);
     }
+}
+
+template <class M, int W>
+__global__ void __launch_bounds__(64 * W, 1) force_sym_square(const SymParamsT<typename M::V4, typename M::S> p)
+{
+    __shared__ typename M::V4 sh[64 * W * M::BPL];
+    float m0 = 0.0f;
+    if (eq_uniform(p.eqm, p.eq_gen, &m0)) force_sym_square_t<M, W, true>(p, sh, (typename M::S)m0);
+    else force_sym_square_t<M, W, false>(p, sh, (typename M::S)m0);
 }
 
 // The same kernel compiled for EXACTLY WPS waves per SIMD (amdgpu_waves_per_eu). Measured alternative, tools/symbench.hip only: it does
@@ -814,10 +933,12 @@ struct RunParams {
     long nunits;   // run_prefix(nbi)
     RunLayout r;
     float eps2;
+    const MassInfo* eqm;   // mass_scan's verdict on the n bodies (nullptr: general path)
+    unsigned int eq_gen;
 };
 
-template <class M>
-__global__ void __launch_bounds__(64) force_sym_run(const RunParams p)
+template <class M, bool EQ>
+__device__ __forceinline__ void force_sym_run_t(const RunParams& p, const float m0)
 {
     constexpr int BPL = M::BPL;
     const int lane = threadIdx.x;
@@ -838,7 +959,7 @@ __global__ void __launch_bounds__(64) force_sym_run(const RunParams p)
     const int rot = ((lane + 16) & 63) << 2;
     auto fetch = [&](int c) {
         const int j = c * 64 + lane;
-        return j < p.n ? p.x[j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        return j < p.n ? p.x[j] : pad4<float4, EQ>();
     };
     M t;
     t.set_eps2(p.eps2);
@@ -850,7 +971,7 @@ __global__ void __launch_bounds__(64) force_sym_run(const RunParams p)
 #pragma unroll
         for (int k = 0; k < BPL; ++k) {
             const int i = ibase + k * 64;
-            t.set(k, i < p.n ? p.x[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+            t.set(k, i < p.n ? p.x[i] : pad4<float4, EQ>());
         }
         float4* const out_j = p.slabs + (size_t)I * p.stride;
         float4 nxt = fetch(c);
@@ -860,29 +981,41 @@ __global__ void __launch_bounds__(64) force_sym_run(const RunParams p)
             if (c < (I + 1) * BPL) {  // a chunk of the block itself: both orders of every pair occur, one side each
                 float4 aj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 for (int ph = 0; ph < 4; ++ph) {
-                    sym_row_pass<false>(t, bj, aj);
-                    bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot); bj.w = next_row(bj.w, rot);
+                    sym_row_pass<false, EQ>(t, bj, aj);
+                    bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot);
+                    if (!EQ) bj.w = next_row(bj.w, rot);
                 }
             } else {
                 float4 aj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 for (int ph = 0; ph < 4; ++ph) {
-                    sym_row_pass<true>(t, bj, aj);
-                    bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot); bj.w = next_row(bj.w, rot);
+                    sym_row_pass<true, EQ>(t, bj, aj);
+                    bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot);
+                    if (!EQ) bj.w = next_row(bj.w, rot);
                     aj.x = next_row(aj.x, rot); aj.y = next_row(aj.y, rot); aj.z = next_row(aj.z, rot);
                 }
                 const int j = c * 64 + lane;  // back in the home lane after four row moves
+                if (EQ) { aj.x *= m0; aj.y *= m0; aj.z *= m0; }
                 aj.w = 0.0f;
                 if (j < p.n) out_j[j] = aj;
             }
         }
         const int seg = (int)(g - row0 / p.r.L);  // this worker's ordinal among the workers of row I
         float4* const out_i = p.slabs + (size_t)(I + seg) * p.stride;
+        if (EQ) t.scale(m0);
 #pragma unroll
         for (int k = 0; k < BPL; ++k) {
             const int i = ibase + k * 64;
             if (i < p.n) out_i[i] = t.acc(k);
         }
     }
+}
+
+template <class M>
+__global__ void __launch_bounds__(64) force_sym_run(const RunParams p)
+{
+    float m0 = 0.0f;
+    if (eq_uniform(p.eqm, p.eq_gen, &m0)) force_sym_run_t<M, true>(p, m0);
+    else force_sym_run_t<M, false>(p, m0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -999,36 +1132,36 @@ struct BalParams {
     int n;
     BalLayout y;
     float eps2;
+    const MassInfo* eqm;   // mass_scan's verdict on the n bodies (nullptr: general path)
+    unsigned int eq_gen;
 };
 
-template <int S, bool SYM, class M>
+template <int S, bool SYM, bool EQ = false, class M>
 __device__ __forceinline__ void sym_step_if(M& t, const typename M::V4& bj, typename M::V4& aj, const int ta, const int tb)
 {
-    if (S >= ta && S < tb) sym_step<S, SYM>(t, bj, aj);  // ta, tb are wave-uniform: a scalar branch around the step
+    if (S >= ta && S < tb) sym_step<S, SYM, EQ>(t, bj, aj);  // ta, tb are wave-uniform: a scalar branch around the step
 }
 
 // rotations [ta, tb) of one row phase
-template <bool SYM, class M>
+template <bool SYM, bool EQ = false, class M>
 __device__ __forceinline__ void sym_row_range(M& t, const typename M::V4& bj, typename M::V4& aj, const int ta, const int tb)
 {
     if (ta == 0 && tb == 16) {   // a whole phase: straight-line code, the scheduler may overlap consecutive rotations
-        sym_row_pass<SYM>(t, bj, aj);
+        sym_row_pass<SYM, EQ>(t, bj, aj);
         return;
     }
-    sym_step_if<0, SYM>(t, bj, aj, ta, tb);  sym_step_if<1, SYM>(t, bj, aj, ta, tb);  sym_step_if<2, SYM>(t, bj, aj, ta, tb);
-    sym_step_if<3, SYM>(t, bj, aj, ta, tb);  sym_step_if<4, SYM>(t, bj, aj, ta, tb);  sym_step_if<5, SYM>(t, bj, aj, ta, tb);
-    sym_step_if<6, SYM>(t, bj, aj, ta, tb);  sym_step_if<7, SYM>(t, bj, aj, ta, tb);  sym_step_if<8, SYM>(t, bj, aj, ta, tb);
-    sym_step_if<9, SYM>(t, bj, aj, ta, tb);  sym_step_if<10, SYM>(t, bj, aj, ta, tb); sym_step_if<11, SYM>(t, bj, aj, ta, tb);
-    sym_step_if<12, SYM>(t, bj, aj, ta, tb); sym_step_if<13, SYM>(t, bj, aj, ta, tb); sym_step_if<14, SYM>(t, bj, aj, ta, tb);
-    sym_step_if<15, SYM>(t, bj, aj, ta, tb);
+    sym_step_if<0, SYM, EQ>(t, bj, aj, ta, tb);  sym_step_if<1, SYM, EQ>(t, bj, aj, ta, tb);  sym_step_if<2, SYM, EQ>(t, bj, aj, ta, tb);
+    sym_step_if<3, SYM, EQ>(t, bj, aj, ta, tb);  sym_step_if<4, SYM, EQ>(t, bj, aj, ta, tb);  sym_step_if<5, SYM, EQ>(t, bj, aj, ta, tb);
+    sym_step_if<6, SYM, EQ>(t, bj, aj, ta, tb);  sym_step_if<7, SYM, EQ>(t, bj, aj, ta, tb);  sym_step_if<8, SYM, EQ>(t, bj, aj, ta, tb);
+    sym_step_if<9, SYM, EQ>(t, bj, aj, ta, tb);  sym_step_if<10, SYM, EQ>(t, bj, aj, ta, tb); sym_step_if<11, SYM, EQ>(t, bj, aj, ta, tb);
+    sym_step_if<12, SYM, EQ>(t, bj, aj, ta, tb); sym_step_if<13, SYM, EQ>(t, bj, aj, ta, tb); sym_step_if<14, SYM, EQ>(t, bj, aj, ta, tb);
+    sym_step_if<15, SYM, EQ>(t, bj, aj, ta, tb);
 }
 
-template <class M, int WV>
-__device__ __forceinline__ void force_sym_bal_body(const BalParams& p)
+template <class M, int WV, bool EQ>
+__device__ __forceinline__ void force_sym_bal_body_t(const BalParams& p, float4 (*const sh)[64 * M::BPL], int* const sh_row, const float m0)
 {
     constexpr int BPL = M::BPL;
-    __shared__ float4 sh[WV][64 * BPL];
-    __shared__ int sh_row[WV];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = blockIdx.x * WV + w;
@@ -1041,7 +1174,7 @@ __device__ __forceinline__ void force_sym_bal_body(const BalParams& p)
     // chunk c as seen in row phase ph: lane l holds body (l + 16*ph) & 63 of the chunk
     auto fetch = [&](int c, int ph) {
         const int j = c * 64 + ((lane + 16 * ph) & 63);
-        return j < p.n ? p.x[j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        return j < p.n ? p.x[j] : pad4<float4, EQ>();
     };
     M t;
     t.set_eps2(p.eps2);
@@ -1052,7 +1185,7 @@ __device__ __forceinline__ void force_sym_bal_body(const BalParams& p)
 #pragma unroll
         for (int k = 0; k < BPL; ++k) {
             const int i = ibase + k * 64;
-            t.set(k, i < p.n ? p.x[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+            t.set(k, i < p.n ? p.x[i] : pad4<float4, EQ>());
         }
         float4 nxt = fetch(I * BPL + ((s >> 6) - row0), (s & 63) >> 4);
         while (s < seg1) {
@@ -1068,15 +1201,19 @@ __device__ __forceinline__ void force_sym_bal_body(const BalParams& p)
             if (c < (I + 1) * BPL) {  // a chunk of the block itself: both orders of every pair occur, one side each
                 for (int ph = ph0; ph <= ph1; ++ph) {
                     const int ta = ph == ph0 ? (q0 & 15) : 0, tb = ph == ph1 ? ((q1 - 1) & 15) + 1 : 16;
-                    sym_row_range<false>(t, bj, aj, ta, tb);
-                    if (ph < ph1) { bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot); bj.w = next_row(bj.w, rot); }
+                    sym_row_range<false, EQ>(t, bj, aj, ta, tb);
+                    if (ph < ph1) {
+                        bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot);
+                        if (!EQ) bj.w = next_row(bj.w, rot);
+                    }
                 }
             } else {
                 for (int ph = ph0; ph <= ph1; ++ph) {
                     const int ta = ph == ph0 ? (q0 & 15) : 0, tb = ph == ph1 ? ((q1 - 1) & 15) + 1 : 16;
-                    sym_row_range<true>(t, bj, aj, ta, tb);
+                    sym_row_range<true, EQ>(t, bj, aj, ta, tb);
                     if (ph < ph1) {
-                        bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot); bj.w = next_row(bj.w, rot);
+                        bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot);
+                        if (!EQ) bj.w = next_row(bj.w, rot);
                         aj.x = next_row(aj.x, rot); aj.y = next_row(aj.y, rot); aj.z = next_row(aj.z, rot);
                     }
                 }
@@ -1084,11 +1221,13 @@ __device__ __forceinline__ void force_sym_bal_body(const BalParams& p)
                 // record = row I's run of the chunk's inbox, piece = this worker's ordinal among the workers sharing the unit
                 const int piece = g - (int)(((unsigned)u << 6) / (unsigned)y.L);
                 float4* const out_j = p.inbox + ((size_t)c * y.smax + I * y.pmax + piece) * 64;
+                if (EQ) { aj.x *= m0; aj.y *= m0; aj.z *= m0; }
                 aj.w = 0.0f;
                 out_j[(lane + 16 * ph1) & 63] = aj;
             }
             s = uend;
         }
+        if (EQ) t.scale(m0);   // the row's I-side sums are complete (t.set starts the next row from zero)
         if (s < s1) {
             // the worker goes on into the next row: these I-side sums are complete, one record in the inbox of each of the block's
             // chunks (after the J-side runs of the rows above)
@@ -1125,6 +1264,16 @@ __device__ __forceinline__ void force_sym_bal_body(const BalParams& p)
         const int c = my_last_row * BPL + k;
         if (c < y.ncht) p.inbox[((size_t)c * y.smax + rec) * 64 + lane] = a;
     }
+}
+
+template <class M, int WV>
+__device__ __forceinline__ void force_sym_bal_body(const BalParams& p)
+{
+    __shared__ float4 sh[WV][64 * M::BPL];
+    __shared__ int sh_row[WV];
+    float m0 = 0.0f;
+    if (eq_uniform(p.eqm, p.eq_gen, &m0)) force_sym_bal_body_t<M, WV, true>(p, sh, sh_row, m0);
+    else force_sym_bal_body_t<M, WV, false>(p, sh, sh_row, m0);
 }
 
 template <class M, int WV>

@@ -109,6 +109,17 @@ class Context:
         """The fused small-N step (force + integrate in one launch): -1 where measurements prefer it, 0 never, 1 always (FAST)."""
         check(self._lib.nbody_ctx_set_fused(self._h, mode))
 
+    def set_equal_mass(self, mode: int) -> None:
+        """Equal-mass path of the symmetric kernels (decided on the device, per launch): -1 / 1 wherever the scan finds one common
+        mass, 0 never."""
+        check(self._lib.nbody_ctx_set_equal_mass(self._h, mode))
+
+    def equal_mass_verdict(self) -> dict:
+        """What the last device-side mass scan found: {"scanned": bool, "uniform": bool, "mass": m0}. Synchronises the stream."""
+        sc, un, m = C.c_int(), C.c_int(), C.c_float()
+        check(self._lib.nbody_ctx_equal_mass_verdict(self._h, C.byref(sc), C.byref(un), C.byref(m)))
+        return {"scanned": bool(sc.value), "uniform": bool(un.value), "mass": m.value}
+
     def set_workspace_limit(self, nbytes: int = 0, fail_above: bool = False) -> None:
         """Cap on one partial-sum workspace (0 = automatic: min(96 GiB, half of the free device memory)). Shapes that need
         more are not chosen; the step falls back towards the one-sided kernel. fail_above=True is the test hook of nbody.h."""

@@ -83,7 +83,7 @@ def test_one_sided_default_shape(kernels):
 
 
 def test_square_only_kernels_keep_the_occupancy_of_the_general_ones(nb, kernels):
-    for bpl in (10, 8):
+    for bpl in (10,):
         r = _get(kernels, f"nbk::force_sym_square<nbk::SymPacked<{bpl}>, 4>")
         assert r["Occupancy"] == nb.load().nbody_plan_symmetric_occupancy(bpl), r
         assert r["LDS Size"] == 64 * 4 * bpl * 16

@@ -1235,3 +1235,149 @@ def test_autotune_measures_and_sets_the_knobs(nb, oracle):
     ctx = nb.engine.Context(kernel=nb.KERNEL_STRICT)
     with pytest.raises(nb.NBodyError):
         ctx.autotune(torch.zeros((64, 4), device="cuda"))
+
+
+# ---- equal-mass path of the symmetric kernels (decided on the device, per launch) -----------------------------------
+
+def _accel_all(nb, x0, eq_mode, kernel=None):
+    ctx = nb.engine.Context(kernel=nb.KERNEL_FAST if kernel is None else kernel)
+    ctx.set_equal_mass(eq_mode)
+    n = len(x0)
+    x = torch.from_numpy(x0).cuda()
+    a = torch.full((n, 4), float("nan"), device="cuda")
+    ctx.accel_range(x, a, 0, n, 0, n)
+    ctx.sync()
+    return a.cpu().numpy(), ctx
+
+
+@pytest.mark.parametrize("n,kind", [(20000, "balanced"), (65536, "runs"), (100003, "runs"), (200000, "symmetric"), (262144, "symmetric")])
+def test_equal_mass_path_vs_general_path(nb, oracle, n, kind):
+    """Plummer bodies all carry the mass 1/N: the device-side scan finds them uniform and the symmetric kernel of every
+    decomposition (balanced runs, unit runs, block pairs; ragged sizes with padding lanes) accumulates sum w r and applies the
+    common mass once. Against the general path (switched off on a second context): a rounding-level difference; against the
+    fp64-accumulated CPU sums at both ends of the array: the usual 1e-5; exact mass linearity; bitwise repeat."""
+    x0 = nb.engine.seeded_bodies(n, 1, 2024)
+    assert np.all(x0[:, 3] == x0[0, 3])
+    a_eq, ctx = _accel_all(nb, x0, -1)
+    info = ctx.step_info(n)
+    assert info[kind] and (kind == "symmetric" or info["symmetric"]), info
+    verdict = ctx.equal_mass_verdict()
+    assert verdict["scanned"] and verdict["uniform"] and verdict["mass"] == x0[0, 3]
+    a_gen, ctx0 = _accel_all(nb, x0, 0)
+    assert not ctx0.equal_mass_verdict()["scanned"]
+    scale = np.abs(a_gen[:, :3]).max()
+    assert np.isfinite(a_eq).all() and np.all(a_eq[:, 3] == 0)
+    assert np.abs(a_eq - a_gen)[:, :3].max() <= 2e-6 * scale
+    # the other path did run: different rounding — unless the common mass is a power of two (N = 65536, 262144: 1/N), where
+    # scaling is exact and m0 * sum(w r) == sum((m0 w) r) bit for bit
+    assert np.array_equal(a_eq, a_gen) == (np.frexp(x0[0, 3])[0] == 0.5)
+    for i0 in (0, n - 200):
+        truth = oracle.accel_range(x0, i0, i0 + 200, 0, n, eps2=0.002, f64acc=True)
+        assert np.abs(a_eq[i0:i0 + 200] - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 1e-5
+    again, _ = _accel_all(nb, x0, -1)
+    assert np.array_equal(again, a_eq)
+    x4 = x0.copy(); x4[:, 3] *= 4
+    a4, _ = _accel_all(nb, x4, -1)
+    assert np.array_equal(a4[:, :3], 4 * a_eq[:, :3])
+
+
+@pytest.mark.parametrize("n", [20000, 65536, 200000])
+def test_one_different_body_takes_the_general_path_bit_for_bit(nb, oracle, n):
+    """The scan must see EVERY body: one mass that differs in its last bit (first, middle or last body of the array), a
+    coordinate beyond 1e15 or a NaN send the launch down the general path — the same bits as with the equal-mass path
+    switched off."""
+    x0 = nb.engine.seeded_bodies(n, 1, 7)
+    for where in (0, n // 2 + 1, n - 1):
+        x1 = x0.copy()
+        x1[where, 3] = np.nextafter(x1[where, 3], np.float32(1.0))
+        a_on, ctx = _accel_all(nb, x1, -1)
+        v = ctx.equal_mass_verdict()
+        assert v["scanned"] and not v["uniform"], (where, v)
+        a_off, _ = _accel_all(nb, x1, 0)
+        assert np.array_equal(a_on, a_off), where
+    x2 = x0.copy()
+    x2[n // 3, 0] = 3e15                                         # uniform masses, but a body the far-away padding is not far from
+    a_on, ctx = _accel_all(nb, x2, -1)
+    assert not ctx.equal_mass_verdict()["uniform"]
+    a_off, _ = _accel_all(nb, x2, 0)
+    assert np.array_equal(a_on, a_off)
+    x3 = x0.copy()
+    x3[5, 1] = np.nan
+    a_on, ctx = _accel_all(nb, x3, -1)
+    assert not ctx.equal_mass_verdict()["uniform"]
+    a_off, _ = _accel_all(nb, x3, 0)
+    assert np.array_equal(a_on, a_off, equal_nan=True)
+
+
+def test_equal_mass_cross_launch_and_whole_steps(nb, oracle):
+    """nbody_accel_cross (two disjoint ranges, the source run wrapping round the array) on
+    the equal-mass path: both sides' sums against the CPU; a run that contains one heavier body: the general path, same bits as
+    with the path switched off. Whole steps (N = 65536, 5 steps): positions of the two paths agree to 1e-6 of the scale radius,
+    and the reference's own initial conditions (random masses) never take the path."""
+    n = 60000
+    x0 = nb.engine.seeded_bodies(n, 1, 99)
+    x = torch.from_numpy(x0).cuda()
+    i0, i1, j0, cnt = 10000, 30000, 50000, 19000                 # sources 50000..59999, 0..8999
+    src = np.r_[np.arange(j0, n), np.arange(0, j0 + cnt - n)]
+    res = {}
+    for mode in (-1, 0):
+        ctx = nb.engine.Context()
+        ctx.set_equal_mass(mode)
+        ai = torch.zeros((i1 - i0, 4), device="cuda")
+        aj = torch.zeros((cnt, 4), device="cuda")
+        ctx.accel_cross(x, ai, i0, i1, False, j0, cnt, aj)
+        ctx.sync()
+        res[mode] = (ai.cpu().numpy(), aj.cpu().numpy())
+        if mode == -1:
+            assert ctx.equal_mass_verdict()["uniform"]
+    xs = np.concatenate([x0[i0:i1], x0[src]])
+    ti = oracle.accel_range(xs, 0, 256, i1 - i0, len(xs), eps2=0.002, f64acc=True)
+    tj = oracle.accel_range(xs, i1 - i0 + cnt - 256, i1 - i0 + cnt, 0, i1 - i0, eps2=0.002, f64acc=True)
+    for mode in (-1, 0):
+        assert np.abs(res[mode][0][:256] - ti)[:, :3].max() / np.abs(ti[:, :3]).max() <= 1e-5
+        assert np.abs(res[mode][1][-256:] - tj)[:, :3].max() / np.abs(tj[:, :3]).max() <= 1e-5
+    assert not np.array_equal(res[-1][0], res[0][0])             # 1/60000 is not a power of two: the roundings differ
+    x1 = x0.copy(); x1[3, 3] *= 2                                # a heavier body inside the wrapped part of the source run
+    xh = torch.from_numpy(x1).cuda()
+    out = {}
+    for mode in (-1, 0):
+        ctx = nb.engine.Context()
+        ctx.set_equal_mass(mode)
+        ai = torch.zeros((i1 - i0, 4), device="cuda")
+        aj = torch.zeros((cnt, 4), device="cuda")
+        ctx.accel_cross(xh, ai, i0, i1, False, j0, cnt, aj)
+        ctx.sync()
+        out[mode] = (ai.cpu().numpy(), aj.cpu().numpy())
+        if mode == -1:
+            assert not ctx.equal_mass_verdict()["uniform"]
+    assert np.array_equal(out[-1][0], out[0][0]) and np.array_equal(out[-1][1], out[0][1])
+    # whole steps
+    n = 65536
+    x0 = nb.engine.seeded_bodies(n, 1, 5)
+    fin = {}
+    for mode in (-1, 0):
+        sim = nb.engine.Simulation(x0, dt=0.01, eps2=0.002)
+        sim.ctx.set_equal_mass(mode)
+        sim.run(5)
+        fin[mode] = sim.state()
+        assert sim.ctx.equal_mass_verdict()["uniform"] == (mode == -1)
+    assert np.abs(fin[-1][0] - fin[0][0])[:, :3].max() <= 1e-6
+    assert np.abs(fin[-1][2] - fin[0][2])[:, :3].max() <= 3e-6 * np.abs(fin[0][2][:, :3]).max()
+    xr = nb.engine.seeded_bodies(n, 0, 5)                        # the reference's kind of initial conditions: random masses
+    sim = nb.engine.Simulation(xr, dt=0.1, eps2=0.002)
+    sim.run(2)
+    v = sim.ctx.equal_mass_verdict()
+    assert v["scanned"] and not v["uniform"]
+
+
+def test_equal_mass_zero_and_negative_common_mass(nb, oracle):
+    """A common mass of zero gives exact zeros, a negative one the mirrored field; nothing non-finite appears."""
+    n = 30000
+    x0 = nb.engine.seeded_bodies(n, 1, 3)
+    ref, _ = _accel_all(nb, x0, -1)
+    xz = x0.copy(); xz[:, 3] = 0.0
+    az, ctx = _accel_all(nb, xz, -1)
+    assert ctx.equal_mass_verdict()["uniform"] and np.all(az == 0)
+    xn = x0.copy(); xn[:, 3] *= -1
+    an, _ = _accel_all(nb, xn, -1)
+    assert np.array_equal(an[:, :3], -ref[:, :3])

@@ -195,6 +195,7 @@ struct SymVariant {
     std::string name;
     int B;
     std::function<void(const nbk::SymParams&, int grid)> launch;
+    bool eq = false;   // run nbk::mass_scan first and hand its verdict to the kernel (the equal-mass path when the bodies are uniform)
 };
 
 template <class M, int W, int MINW = 1>
@@ -295,6 +296,20 @@ int main(int argc, char** argv)
     printf("N=%d %s  one-sided vs fp64 truth: %.3g of max|a|\n", n, plummer ? "plummer" : "cube", err_vs_truth(a_ref));
 
     std::vector<SymVariant> vars;
+    nbk::MassInfo* dinfo;
+    CK(hipMalloc(&dinfo, sizeof(nbk::MassInfo)));
+    CK(hipMemset(dinfo, 0, sizeof(nbk::MassInfo)));
+    unsigned eq_gen = 0;
+    if (getenv("SYMBENCH_EQ")) {   // A/B of the equal-mass path (same kernels, verdict pointer null or set), interleaved
+        for (int rep = 0; rep < 2; ++rep) {
+            vars.push_back({"sym bpl10 w4 SQUARE general path", 2560, [](const nbk::SymParams& p, int grid) { nbk::force_sym_square<nbk::SymPacked<10>, 4><<<grid, 256>>>(p); }});
+            vars.push_back({"sym bpl10 w4 SQUARE equal-mass", 2560, [](const nbk::SymParams& p, int grid) { nbk::force_sym_square<nbk::SymPacked<10>, 4><<<grid, 256>>>(p); }, true});
+            vars.push_back(sym_variant<nbk::SymPacked<10>, 4>("sym bpl10 w4 general kernel, general path"));
+            { auto v = sym_variant<nbk::SymPacked<10>, 4>("sym bpl10 w4 general kernel, equal-mass"); v.eq = true; vars.push_back(v); }
+            vars.push_back(sym_variant<nbk::SymPacked<8>, 4>("sym bpl8 w4 general path"));
+            { auto v = sym_variant<nbk::SymPacked<8>, 4>("sym bpl8 w4 equal-mass"); v.eq = true; vars.push_back(v); }
+        }
+    } else {
     vars.push_back(sym_variant<nbk::SymPacked<10>, 4>("sym packed bpl10 w4 (B=2560)"));
     vars.push_back({"sym bpl10 w4 SQUARE-only kernel", 2560, [](const nbk::SymParams& p, int grid) { nbk::force_sym_square<nbk::SymPacked<10>, 4><<<grid, 256>>>(p); }});
     vars.push_back({"sym bpl10 w4 waves_per_eu(2,2)", 2560, [](const nbk::SymParams& p, int grid) { nbk::force_sym_wps<nbk::SymPacked<10>, 4, 2><<<grid, 256>>>(p); }});
@@ -303,8 +318,8 @@ int main(int argc, char** argv)
     vars.push_back({"sym bpl8 w4 waves_per_eu(3,3)", 2048, [](const nbk::SymParams& p, int grid) { nbk::force_sym_wps<nbk::SymPacked<8>, 4, 3><<<grid, 256>>>(p); }});
     vars.push_back(sym_variant<nbk::SymPacked<8>, 4>("sym packed bpl8 w4 (B=2048)"));
     vars.push_back({"sym bpl10 w4 SQUARE-only again", 2560, [](const nbk::SymParams& p, int grid) { nbk::force_sym_square<nbk::SymPacked<10>, 4><<<grid, 256>>>(p); }});
-    vars.push_back({"sym bpl8 w4 SQUARE-only", 2048, [](const nbk::SymParams& p, int grid) { nbk::force_sym_square<nbk::SymPacked<8>, 4><<<grid, 256>>>(p); }});
     vars.push_back(sym_variant<nbk::SymPacked<10>, 4>("sym packed bpl10 w4 (B=2560) again"));
+    }
     const double pairs = (double)n * n;
     const float t_ref = median_ms(one_sided, reps);
     printf("%-34s %8.3f ms  %.3e pairs/s  %.1f%% of 157.3 TF\n", "one-sided lds packed bpl4 t2048", t_ref, pairs / t_ref * 1e3,
@@ -316,6 +331,16 @@ int main(int argc, char** argv)
         sp.x = dx; sp.slabs_i = slabs; sp.slabs_j = slabs; sp.ni = n; sp.nj = n; sp.i0 = 0; sp.j0 = 0; sp.wrap = 0; sp.nbi = nb; sp.nbj = nb;
         sp.stride_i = n; sp.stride_j = n; sp.rect = 0; sp.eps2 = eps2;
         const int grid = nb * (nb - 1) / 2 + nb;
+        if (v.eq) {
+            nbk::MassScanParams mp{};
+            mp.x = dx; mp.i0 = 0; mp.ni = n; mp.j0 = 0; mp.nj = 0; mp.wrap = 0; mp.out = dinfo; mp.gen = ++eq_gen;
+            nbk::mass_scan<<<std::min((n + 255) / 256, 1024), 256>>>(mp);
+            CK(hipGetLastError());
+            sp.eqm = dinfo; sp.eq_gen = eq_gen;
+            nbk::MassInfo hi{};
+            CK(hipMemcpy(&hi, dinfo, sizeof hi, hipMemcpyDeviceToHost));
+            printf("  mass_scan: %s (m0 = %g)\n", hi.bad_gen != eq_gen ? "uniform" : "NOT uniform", hi.m0);
+        }
         auto run = [&] {
             v.launch(sp, grid);
             reduce(da_sym, nb);
