@@ -216,6 +216,13 @@ def main():
     ap.add_argument("--jsplit", type=int, default=0)
     ap.add_argument("--sym-waves", type=int, default=0)
     ap.add_argument("--sym-bpl", type=int, default=0)
+    ap.add_argument("--masses", default="init", choices=["init", "random"], help="init: as the initial conditions give them (Plummer: every body 1/N, "
+                    "which the symmetric kernels' equal-mass path picks up; cube: the reference's random masses); random: Plummer positions "
+                    "with masses drawn uniformly over a decade, as the reference's fill_with_random4 does, total 1 - the general path")
+    ap.add_argument("--equal-mass", default="auto", choices=["auto", "off"], help="off: nbody_ctx_set_equal_mass(0), the general pair "
+                    "arithmetic whatever the masses")
+    ap.add_argument("--no-general-path", action="store_true", help="skip the extra repeats that time the general pair arithmetic when the "
+                    "timed steps took the equal-mass path (profile runs: only the timed kernels in the trace)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="f64 = the build's own double-precision variant "
                     "(BASELINE configs[4]; single GPU only)")
@@ -286,6 +293,9 @@ def main():
 
     n, scaling = default_workload(world, args.n, args.scaling)
     x0 = nbody_amd.engine.seeded_bodies(n, args.init, 12345)
+    if args.masses == "random" and args.init == 1:
+        u = np.random.RandomState(12345).uniform(1.0, 10.0, n)
+        x0[:, 3] = (u / u.sum()).astype(np.float32)
     kernel = {"fast": nbody_amd.KERNEL_FAST, "onesided": nbody_amd.KERNEL_ONESIDED, "symmetric": nbody_amd.KERNEL_SYMMETRIC}[args.kernel]
     kopts = dict(kernel=kernel, tile=args.tile, bodies_per_lane=args.bpl, jsplit=args.jsplit)
     red_dev = dev if args.backend == "nccl" else "cpu"
@@ -358,6 +368,9 @@ def main():
         info["evaluated_pairs"] += cross
         info["schedule"] = {0: "canonical", 1: "onesided", 2: "symmetric"}[plan.schedule]
         info["cross_launches"] = [[plan.launch[l].i0, plan.launch[l].i1, plan.launch[l].j0, plan.launch[l].count] for l in range(plan.n_launches)]
+
+    if args.equal_mass == "off":
+        ctx.set_equal_mass(0)
 
     def barrier():
         sync()
@@ -456,6 +469,32 @@ def main():
     ctx.timing(False)
     comm = sim.comm_report() if multi else None
 
+    # Equal masses (a Plummer sphere: every body 1/N) let the symmetric kernels factor the common mass out of the pair sums; the
+    # decision is taken on the device per launch. Say whether the timed steps took that path, and time the GENERAL path (what a
+    # system with unequal masses, e.g. the reference's own initial conditions, gets) on the same bodies right here.
+    equal_mass = None
+    if True:
+        v = ctx.equal_mass_verdict()
+        equal_mass = {"path_taken": bool(v["scanned"] and v["uniform"]), "decided": "on the device, per launch (nbk::mass_scan); nbody_ctx_set_equal_mass(0) or --equal-mass off disables it",
+                      "masses": ("all equal: %.9g" % v["mass"]) if v["scanned"] and v["uniform"] else "not all equal (or never scanned): general pair arithmetic"}
+        # (a collective decision: every rank times the general path or none does)
+        equal_mass["path_taken_on_every_rank"] = max_over_ranks(0.0 if equal_mass["path_taken"] else 1.0) == 0.0
+        if equal_mass["path_taken_on_every_rank"] and not args.no_general_path:
+            ctx.set_equal_mass(0)
+            run(2)
+            gen = []
+            for _ in range(3):
+                barrier()
+                t0 = time.perf_counter()
+                run(args.steps)
+                barrier()
+                gen.append(max_over_ranks(time.perf_counter() - t0))
+            ctx.set_equal_mass(-1)
+            g = statistics.median(gen)
+            equal_mass["general_path"] = {"ms_per_step": g / args.steps * 1e3, "value": float(n) * n * args.steps / g, "unit": "pairs/s",
+                                          "frac_of_peak_at_20_flop": FLOP_PER_PAIR * float(n) * n * args.steps / g / 1e12 / ((FP64_VECTOR_PEAK_TFLOPS if f64 else FP32_VECTOR_PEAK_TFLOPS) * world),
+                                          "repeats": 3, "note": "same bodies, same run, equal-mass path switched off: what unequal masses get"}
+
     elapsed = statistics.median(repeats)
     pairs_step = float(n) * n
     value = pairs_step * args.steps / elapsed
@@ -534,6 +573,9 @@ def main():
                                                                   (", every unordered pair once across the ranks, J-side sums exchanged (grouped send/recv)" if info.get("schedule") == "symmetric" else "")),
             "kernel": nbody_amd.load().nbody_version().decode(),
             "launch": info,
+            "masses": ("Plummer: every body 1/N" if args.init == 1 and args.masses == "init" else "Plummer positions, masses uniform over a decade (total 1)"
+                       if args.init == 1 else "the reference's fill_with_random4 range"),
+            **({"equal_mass": equal_mass} if equal_mass else {}),
             "gflops_at_20_flop_per_pair": value * FLOP_PER_PAIR / 1e9,
             **({"fp32_vs_fp64": fp_diff} if fp_diff else {}),
             **({"comm_rank0": comm} if comm else {}),
@@ -568,7 +610,10 @@ def main():
                      "fp32 vector-ALU bound (no MFMA, HBM traffic is O(N) per step); peak = 157.3 TFLOP/s fp32 vector = fp32 MFMA peak. "
                      "achieved/frac: 20 FLOP x interactions applied (N^2, the metric's convention: SURVEY.md 8d's per-unit figure x the units one launch processes); "
                      "achieved_evaluated/frac_evaluated: 20 FLOP x pair evaluations actually EXECUTED (the symmetric kernel evaluates each unordered pair once and "
-                     "applies it to both bodies) — the figure to read as ALU work done per second"),
+                     "applies it to both bodies) — the figure to read as ALU work done per second" +
+                     ("; the bodies all carry the same mass, so the kernel took its equal-mass path (14 instead of 16 packed ops per two pair evaluations: the common "
+                      "mass is factored out of the sums and applied once per stored partial sum) — config.equal_mass.general_path is the same run with that path off"
+                      if equal_mass and equal_mass["path_taken"] else "")),
         },
     }
     if rank == 0:

@@ -627,7 +627,8 @@ int ensure_inbox(nbody_ctx* c, const BalShape& b)
 // reads the verdict itself. *q stays nullptr when the path is switched off (or the verdict slots cannot be allocated).
 constexpr int kEqMinBodies = 4096;   // below this the scan launch costs more than the path saves
 
-int eq_scan(nbody_ctx* c, int slot, const float4* x, int i0, int ni, int j0, int nj, int wrap, const nbk::MassInfo** q, unsigned int* gen)
+template <class V4>
+int eq_scan(nbody_ctx* c, int slot, const V4* x, int i0, int ni, int j0, int nj, int wrap, const nbk::MassInfo** q, unsigned int* gen)
 {
     *q = nullptr;
     *gen = 0;
@@ -641,14 +642,14 @@ int eq_scan(nbody_ctx* c, int slot, const float4* x, int i0, int ni, int j0, int
         HIP_TRY(hipMemset(c->eqm, 0, 2 * sizeof(nbk::MassInfo)));
     }
     if (++c->eq_gen == 0) ++c->eq_gen;   // 0 is what a fresh slot holds
-    nbk::MassScanParams mp{};
+    nbk::MassScanParamsT<V4> mp{};
     mp.x = x;
     mp.i0 = i0; mp.ni = ni; mp.j0 = j0; mp.nj = nj; mp.wrap = wrap;
     mp.out = c->eqm + slot;
     mp.gen = c->eq_gen;
     int blocks = (ni + nj + 255) / 256;
     if (blocks > 1024) blocks = 1024;
-    nbk::mass_scan<<<blocks, 256, 0, c->stream>>>(mp);
+    nbk::mass_scan<V4><<<blocks, 256, 0, c->stream>>>(mp);
     HIP_TRY(hipGetLastError());
     c->eq_last_slot = slot;
     *q = c->eqm + slot;
@@ -841,7 +842,7 @@ const char* nbody_last_error(void) { return g_err; }
 
 const char* nbody_version(void)
 {
-    return "nbody_hip 0.3 gfx950 fast=symmetric-dpp(w4,bpl10)|symmetric-balanced-runs(8k-45k)|fused-step(<=8k)|onesided-lds-packed(bpl4,tile2048,u8) strict=ieee-seq f64=symmetric-dpp(w4,bpl6)|lds";
+    return "nbody_hip 0.3 gfx950 fast=symmetric-dpp(w4,bpl10)+equal-mass-path|symmetric-balanced-runs(8k-45k)|fused-step(<=8k)|onesided-lds-packed(bpl4,tile2048,u8) strict=ieee-seq f64=symmetric-dpp(w4,bpl6)+equal-mass-path|lds";
 }
 
 int nbody_device_count(int* count)
@@ -1008,7 +1009,7 @@ int nbody_ctx_equal_mass_verdict(nbody_ctx* c, int* scanned, int* uniform, float
     const bool bad = h[0].bad_gen == c->eq_gen || h[1].bad_gen == c->eq_gen;
     if (scanned) *scanned = 1;
     if (uniform) *uniform = bad ? 0 : 1;
-    if (mass) *mass = h[c->eq_last_slot].m0;
+    if (mass) *mass = (float)h[c->eq_last_slot].m0;
     return NBODY_OK;
 }
 
@@ -1933,6 +1934,7 @@ int nbody_step_f64(nbody_ctx* c, nbody_double4* d_bodies, nbody_double4* d_accel
         sp.ni = n; sp.nj = n; sp.i0 = 0; sp.j0 = 0; sp.wrap = 0;
         sp.nbi = nb; sp.nbj = nb; sp.stride_i = n; sp.stride_j = n; sp.rect = 0;
         sp.eps2 = eps2;
+        if (int rc = eq_scan(c, 0, sp.x, 0, n, 0, 0, 0, &sp.eqm, &sp.eq_gen)) return rc;   // the equal-mass path, in double
         q.slabs = static_cast<const double4*>(c->slabs);
         q.nslab = nb;
         q.slab_stride = n;

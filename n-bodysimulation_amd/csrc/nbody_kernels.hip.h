@@ -309,29 +309,42 @@ __global__ void __launch_bounds__(kWG, MINW) force_sgpr(const ForceParams p)
 // mass_scan decides on the device, in stream order (no host round trip): it compares every body of the launch's ranges with the
 // first one and stamps `bad_gen` with the launch's generation number when one differs (or a coordinate is beyond kEqMaxCoord or
 // not finite, see the padding below); the force kernel takes the equal-mass path when the stamp is not its own generation.
-// Padding bodies (past the end of a range) have no mass to switch them off on that path: they sit at (1e18, 1e18, 1e18), where
-// w = rsq(d)^3 underflows to exactly 0 against every body within kEqMaxCoord of the origin.
+// Padding bodies (past the end of a range) have no mass to switch them off on that path: they sit at (1e18, 1e18, 1e18) (fp64: 1e150),
+// where w = rsq(d)^3 underflows to exactly 0 against every body within kEqMaxCoord of the origin.
 struct MassInfo {
     unsigned int bad_gen;   // generation of the last scan that found the bodies NOT uniform
-    float m0;               // mass of the first body of the last scan
+    unsigned int pad_;
+    double m0;              // mass of the first body of the last scan (a float mass converts exactly)
 };
 constexpr float kEqMaxCoord = 1e15f;
-constexpr float kEqFar = 1e18f;
+// where a padding body sits on the equal-mass path: w = rsq(d)^3 underflows to exactly 0 from there (fp32: d = 3e36, w = 2e-55;
+// fp64: d = 3e300, w = 2e-451) while r itself stays finite, so w * r is an exact zero
+template <class S> __device__ __forceinline__ S eq_far();
+template <> __device__ __forceinline__ float eq_far<float>() { return 1e18f; }
+template <> __device__ __forceinline__ double eq_far<double>() { return 1e150; }
 
-struct MassScanParams {
-    const float4* x;
+__device__ __forceinline__ bool same_bits(const float a, const float b) { return __builtin_bit_cast(unsigned int, a) == __builtin_bit_cast(unsigned int, b); }
+__device__ __forceinline__ bool same_bits(const double a, const double b) { return __builtin_bit_cast(unsigned long long, a) == __builtin_bit_cast(unsigned long long, b); }
+
+template <class V4>
+struct MassScanParamsT {
+    const V4* x;
     int i0, ni;      // first range
     int j0, nj;      // second range (nj = 0: none); indices at or beyond `wrap` continue at body 0 when wrap > 0
     int wrap;
     MassInfo* out;
     unsigned int gen;
 };
+using MassScanParams = MassScanParamsT<float4>;
 
-__global__ void __launch_bounds__(256) mass_scan(const MassScanParams p)
+template <class V4>
+__global__ void __launch_bounds__(256) mass_scan(const MassScanParamsT<V4> p)
 {
-    const unsigned int ref = __builtin_bit_cast(unsigned int, p.x[p.i0].w);
+    using S = decltype(p.x->w);
+    const S ref = p.x[p.i0].w;
     bool bad = false;
     const int total = p.ni + p.nj;
+#pragma unroll 1
     for (int e = (int)blockIdx.x * 256 + (int)threadIdx.x; e < total; e += (int)gridDim.x * 256) {
         int idx;
         if (e < p.ni) idx = p.i0 + e;
@@ -339,24 +352,26 @@ __global__ void __launch_bounds__(256) mass_scan(const MassScanParams p)
             idx = p.j0 + (e - p.ni);
             if (p.wrap && idx >= p.wrap) idx -= p.wrap;
         }
-        const float4 b = p.x[idx];
-        bad |= __builtin_bit_cast(unsigned int, b.w) != ref;
-        bad |= !(__builtin_fabsf(b.x) <= kEqMaxCoord && __builtin_fabsf(b.y) <= kEqMaxCoord && __builtin_fabsf(b.z) <= kEqMaxCoord);
+        const V4 b = p.x[idx];
+        bad |= !same_bits(b.w, ref);   // bit for bit (-0 and +0 differ, a NaN equals only itself)
+        const S lim = (S)kEqMaxCoord;
+        bad |= !((b.x <= lim && b.x >= -lim) && (b.y <= lim && b.y >= -lim) && (b.z <= lim && b.z >= -lim));
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const float m0 = __builtin_bit_cast(float, ref);
-        p.out->m0 = m0;
-        bad |= !(__builtin_fabsf(m0) <= 3.0e38f);   // a NaN or infinite common mass: the general path reproduces it term by term
+        p.out->m0 = (double)ref;
+        bad |= !(ref <= (S)3.0e38 && ref >= (S)-3.0e38);   // a NaN or infinite common mass: the general path reproduces it term by term
     }
     if (bad) p.out->bad_gen = p.gen;   // every writer stores the same value
 }
 
 // the launch's verdict: wave-uniform (scalar loads from a kernel-argument pointer)
-__device__ __forceinline__ bool eq_uniform(const MassInfo* q, const unsigned int gen, float* m0)
+__device__ __forceinline__ bool eq_uniform(const MassInfo* q, const unsigned int gen, double* m0)
 {
     if (!q) return false;
     const unsigned int bad = __builtin_amdgcn_readfirstlane((int)q->bad_gen);
-    *m0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, q->m0)));
+    const long long b = __builtin_bit_cast(long long, q->m0);
+    const int lo = __builtin_amdgcn_readfirstlane((int)b), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    *m0 = __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
     return bad != gen;
 }
 
@@ -414,7 +429,7 @@ template <> __device__ __forceinline__ double4 zero4<double4>() { return make_do
 template <class V4, bool EQ> __device__ __forceinline__ V4 pad4()
 {
     V4 v = zero4<V4>();
-    if (EQ) { v.x = kEqFar; v.y = kEqFar; v.z = kEqFar; }
+    if (EQ) { v.x = eq_far<decltype(v.x)>(); v.y = v.x; v.z = v.x; }
     return v;
 }
 
@@ -768,7 +783,7 @@ template <class M, int W>
 __device__ __forceinline__ void force_sym_body(const SymParamsT<typename M::V4, typename M::S>& p)
 {
     __shared__ typename M::V4 sh[64 * W * M::BPL];
-    float m0 = 0.0f;
+    double m0 = 0.0;
     if (eq_uniform(p.eqm, p.eq_gen, &m0)) force_sym_body_t<M, W, true>(p, sh, (typename M::S)m0);
     else force_sym_body_t<M, W, false>(p, sh, (typename M::S)m0);
 }
@@ -881,7 +896,7 @@ template <class M, int W>
 __global__ void __launch_bounds__(64 * W, 1) force_sym_square(const SymParamsT<typename M::V4, typename M::S> p)
 {
     __shared__ typename M::V4 sh[64 * W * M::BPL];
-    float m0 = 0.0f;
+    double m0 = 0.0;
     if (eq_uniform(p.eqm, p.eq_gen, &m0)) force_sym_square_t<M, W, true>(p, sh, (typename M::S)m0);
     else force_sym_square_t<M, W, false>(p, sh, (typename M::S)m0);
 }
@@ -1011,11 +1026,11 @@ __device__ __forceinline__ void force_sym_run_t(const RunParams& p, const float 
 }
 
 template <class M>
-__global__ void __launch_bounds__(64) force_sym_run(const RunParams p)
+__global__ void __launch_bounds__(64, M::BPL >= 10 ? 2 : 3) force_sym_run(const RunParams p)   // (the waves per SIMD the cost model counts on)
 {
-    float m0 = 0.0f;
-    if (eq_uniform(p.eqm, p.eq_gen, &m0)) force_sym_run_t<M, true>(p, m0);
-    else force_sym_run_t<M, false>(p, m0);
+    double m0 = 0.0;
+    if (eq_uniform(p.eqm, p.eq_gen, &m0)) force_sym_run_t<M, true>(p, (float)m0);
+    else force_sym_run_t<M, false>(p, 0.0f);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1271,9 +1286,9 @@ __device__ __forceinline__ void force_sym_bal_body(const BalParams& p)
 {
     __shared__ float4 sh[WV][64 * M::BPL];
     __shared__ int sh_row[WV];
-    float m0 = 0.0f;
-    if (eq_uniform(p.eqm, p.eq_gen, &m0)) force_sym_bal_body_t<M, WV, true>(p, sh, sh_row, m0);
-    else force_sym_bal_body_t<M, WV, false>(p, sh, sh_row, m0);
+    double m0 = 0.0;
+    if (eq_uniform(p.eqm, p.eq_gen, &m0)) force_sym_bal_body_t<M, WV, true>(p, sh, sh_row, (float)m0);
+    else force_sym_bal_body_t<M, WV, false>(p, sh, sh_row, 0.0f);
 }
 
 template <class M, int WV>

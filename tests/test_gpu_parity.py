@@ -1381,3 +1381,45 @@ def test_equal_mass_zero_and_negative_common_mass(nb, oracle):
     xn = x0.copy(); xn[:, 3] *= -1
     an, _ = _accel_all(nb, xn, -1)
     assert np.array_equal(an[:, :3], -ref[:, :3])
+
+
+def test_equal_mass_path_in_double(nb, oracle):
+    """The fp64 step on the equal-mass path (same scan, padding at 1e150): N = 30001 (ragged) and the general path on the same
+    bodies agree to rounding; both within 1e-12 of the checker's all-double sums; one different mass switches the path off
+    (bit-identical to the path switched off)."""
+    n = 30001
+    x0 = nb.engine.seeded_bodies(n, 1, 17).astype(np.float64)
+    x0[:, 3] = 1.0 / n                                            # a double that is not a rounded float
+    out = {}
+    for mode in (-1, 0):
+        ctx = nb.engine.Context()
+        ctx.set_equal_mass(mode)
+        x = torch.from_numpy(x0).cuda()
+        v = torch.zeros_like(x)
+        a = torch.zeros_like(x)
+        ctx.step_f64(x, a, v, dt=0.01, eps2=0.002, steps=1)
+        ctx.sync()
+        assert ctx.step_info_f64(n)["symmetric"]
+        ver = ctx.equal_mass_verdict()
+        assert ver["scanned"] == (mode == -1) and ver["uniform"] == (mode == -1)
+        out[mode] = a.cpu().numpy()
+    scale = np.abs(out[0][:, :3]).max()
+    assert np.abs(out[-1] - out[0])[:, :3].max() <= 1e-14 * scale and not np.array_equal(out[-1], out[0])
+    for i0 in (0, n - 128):
+        want = oracle.accel_range_f64(x0, i0, i0 + 128, 0, n, eps2=0.002)
+        for mode in (-1, 0):
+            assert np.abs(out[mode][i0:i0 + 128] - want)[:, :3].max() / np.abs(want[:, :3]).max() <= 1e-12
+    x1 = x0.copy(); x1[n - 1, 3] *= 1.0 + 2.0 ** -40
+    res = {}
+    for mode in (-1, 0):
+        ctx = nb.engine.Context()
+        ctx.set_equal_mass(mode)
+        x = torch.from_numpy(x1).cuda()
+        v = torch.zeros_like(x)
+        a = torch.zeros_like(x)
+        ctx.step_f64(x, a, v, dt=0.01, eps2=0.002, steps=1)
+        ctx.sync()
+        if mode == -1:
+            assert not ctx.equal_mass_verdict()["uniform"]
+        res[mode] = a.cpu().numpy()
+    assert np.array_equal(res[-1], res[0])

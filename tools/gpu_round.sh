@@ -14,6 +14,6 @@ timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smok
 [ $rc -eq 0 ] || exit $rc
 timeout -k 10 400 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; rc=$?; echo "bench rc=$rc" | tee -a $OUT/summary.txt; cat $OUT/bench.json
 [ $rc -eq 0 ] || exit $rc
-( cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/prof -- python3 $REPO/bench.py --steps 20 --warmup 5 --repeats 3 --no-cpu-baseline > $REPO/$OUT/bench_prof.json 2> $REPO/$OUT/prof.err ); rc=$?; echo "rocprof rc=$rc" | tee -a $OUT/summary.txt
+( cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/prof -- python3 $REPO/bench.py --steps 20 --warmup 5 --repeats 3 --no-cpu-baseline --no-general-path > $REPO/$OUT/bench_prof.json 2> $REPO/$OUT/prof.err ); rc=$?; echo "rocprof rc=$rc" | tee -a $OUT/summary.txt
 find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -r head -8
 exit $rc

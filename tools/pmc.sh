@@ -11,7 +11,7 @@ cd /tmp
 rocprofv3 -L > $OUT/counters_list.txt 2>&1
 run() {  # name, counters...
   local name=$1; shift
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $REPO/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline $PMC_BENCH_ARGS > $OUT/$name.json 2> $OUT/$name.err
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $REPO/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-general-path $PMC_BENCH_ARGS > $OUT/$name.json 2> $OUT/$name.err
   echo "$name rc=$?"
 }
 run sq1 SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY && \

@@ -334,7 +334,7 @@ int main(int argc, char** argv)
         if (v.eq) {
             nbk::MassScanParams mp{};
             mp.x = dx; mp.i0 = 0; mp.ni = n; mp.j0 = 0; mp.nj = 0; mp.wrap = 0; mp.out = dinfo; mp.gen = ++eq_gen;
-            nbk::mass_scan<<<std::min((n + 255) / 256, 1024), 256>>>(mp);
+            nbk::mass_scan<float4><<<std::min((n + 255) / 256, 1024), 256>>>(mp);
             CK(hipGetLastError());
             sp.eqm = dinfo; sp.eq_gen = eq_gen;
             nbk::MassInfo hi{};
