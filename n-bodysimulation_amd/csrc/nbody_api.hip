@@ -1038,6 +1038,10 @@ int nbody_ctx_reserve(nbody_ctx* c, int n_targets)
     if (n_targets < 0) return fail(NBODY_ERR_INVALID, "n_targets < 0");
     ON_DEVICE(c);
     refresh_ws_cap(c);
+    if (c->eq_mode != 0 && !c->eqm && n_targets >= kEqMinBodies) {   // the verdict slots of the equal-mass scan, ahead of the first step
+        if (hipMalloc(reinterpret_cast<void**>(&c->eqm), 2 * sizeof(nbk::MassInfo)) == hipSuccess) HIP_TRY(hipMemset(c->eqm, 0, 2 * sizeof(nbk::MassInfo)));
+        else { (void)hipGetLastError(); c->eqm = nullptr; }
+    }
     {
         FusedShape fs{};
         if (fused_wanted(c, n_targets, &fs)) (void)ensure_xalt(c, n_targets);   // whole steps of this size run the fused kernel; the workspace below

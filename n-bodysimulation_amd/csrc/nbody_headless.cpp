@@ -60,7 +60,7 @@ static bool read_file(const std::string& path, void* p, size_t bytes)
 
 int main(int argc, char** argv)
 {
-    int n = N_BODIES, steps = 10, kernel = NBODY_KERNEL_FAST, sync_each = 0, interactive = 0, json = 1, ngpu = 1, timeout_s = 900, autotune = 0;
+    int n = N_BODIES, steps = 10, kernel = NBODY_KERNEL_FAST, sync_each = 0, interactive = 0, json = 1, ngpu = 1, timeout_s = 900, autotune = 0, equal_mass = -1;
     bool f64 = false, force_shard = false;
     long steps_done = 0;
     float dt = DT, eps2 = EPS2;
@@ -87,11 +87,12 @@ int main(int argc, char** argv)
         else if (a == "--dump") dump = val();
         else if (a == "--load") load = val();
         else if (a == "--sync-each-step") sync_each = 1;
+        else if (a == "--no-equal-mass") equal_mass = 0;  // nbody_ctx_set_equal_mass(0): the general pair arithmetic whatever the masses
         else if (a == "--autotune") autotune = 1;        // measure the decompositions on this device first (single GPU, fast kernel)
         else if (a == "--interactive") interactive = 1;
         else if (a == "--quiet") json = 0;
         else die("unknown option " + a + "\nusage: nbody_headless [--n N] [--steps K] [--dt f] [--eps2 f] [--init libc|ref|plummer] [--seed S]"
-                 " [--kernel fast|strict|onesided|symmetric] [--autotune] [--ngpu G] [--timeout S] [--shard] [--precision f32|f64] [--dump P] [--load P] [--sync-each-step]"
+                 " [--kernel fast|strict|onesided|symmetric] [--autotune] [--no-equal-mass] [--ngpu G] [--timeout S] [--shard] [--precision f32|f64] [--dump P] [--load P] [--sync-each-step]"
                  " [--interactive]");
     }
     if (interactive) {
@@ -182,7 +183,8 @@ int main(int argc, char** argv)
             bool good = true;
             // 1. local: device, context
             if (nbody_ctx_create(&ctx, r) != NBODY_OK) { note("nbody_ctx_create"); good = false; }
-            else if (nbody_ctx_set_params(ctx, dt, eps2) != NBODY_OK || nbody_ctx_set_kernel(ctx, kernel, 0, 0, 0) != NBODY_OK) { note("context setup"); good = false; }
+            else if (nbody_ctx_set_params(ctx, dt, eps2) != NBODY_OK || nbody_ctx_set_kernel(ctx, kernel, 0, 0, 0) != NBODY_OK ||
+                     nbody_ctx_set_equal_mass(ctx, equal_mass) != NBODY_OK) { note("context setup"); good = false; }
             if (gate.pass(good)) {
                 // 2. collective: the communicator (every rank enters, or none does)
                 if (nbody_comm_rccl_create(&comm, r, ngpu, uid, r) != NBODY_OK) { note("nbody_comm_rccl_create"); good = false; }
@@ -295,6 +297,7 @@ int main(int argc, char** argv)
     ok(nbody_default_ctx(&ctx));                         // the context simulate() uses
     ok(nbody_ctx_set_params(ctx, dt, eps2));
     ok(nbody_ctx_set_kernel(ctx, kernel, 0, 0, 0));
+    ok(nbody_ctx_set_equal_mass(ctx, equal_mass));
     ok(nbody_ctx_reserve(ctx, n));
     if (autotune && kernel == NBODY_KERNEL_FAST && n > 0) {
         int choice = 0;
