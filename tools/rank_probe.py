@@ -45,10 +45,11 @@ for G in args.worlds:
     L.check(lib.nbody_shard_sync(h))
     dt = (time.perf_counter() - t) / args.steps
     force_ms, launches = ctx.timing_read()
+    verdict = ctx.equal_mass_verdict()
     n = args.bodies
     print(json.dumps({"G": G, "rank": rank, "n": n, "shard": plan.shard, "schedule": plan.schedule,
                       "ms_per_step": round(dt * 1e3, 3), "force_ms_per_step": round(force_ms / args.steps, 3),
-                      "force_launches_per_step": launches // args.steps,
+                      "force_launches_per_step": launches // args.steps, "equal_mass": verdict,
                       "rank_interactions_per_s": float("%.4g" % (plan.shard * float(plan.n_pad) / dt)),
                       "job_pairs_per_s_if_all_ranks_equal": float("%.4g" % (float(n) * n / dt))}), flush=True)
     L.check(lib.nbody_shard_destroy(h))
