@@ -731,6 +731,13 @@ int launch_sym_untimed(nbody_ctx* c, const SymShape& y0, const nbk::SymParams& p
         HIP_TRY(hipGetLastError());
         return NBODY_OK;
     }
+    // two disjoint ranges (nbody_accel_cross): the rectangular-only build, 1-3 % ahead of the general one on the equal-mass path
+    // (163 VGPRs, three waves per SIMD; profiles/r03_symbench_rect_*.txt), equal on the general path
+    if (p.rect && key == 410) {
+        nbk::force_sym_rect<SymPacked<10>, 4><<<y.grid, 256, 0, c->stream>>>(p);
+        HIP_TRY(hipGetLastError());
+        return NBODY_OK;
+    }
     switch (key) {
         case 410: nbk::force_sym<SymPacked<10>, 4><<<y.grid, 256, 0, c->stream>>>(p); break;
         case 408: nbk::force_sym<SymPacked<8>, 4><<<y.grid, 256, 0, c->stream>>>(p); break;

@@ -901,6 +901,86 @@ __global__ void __launch_bounds__(64 * W, 1) force_sym_square(const SymParamsT<t
     else force_sym_square_t<M, W, false>(p, sh, (typename M::S)m0);
 }
 
+// The RECTANGULAR case alone (two disjoint ranges, rect == 1; the J run may wrap): what nbody_accel_cross launches — seven eighths of a
+// rank's pairs in an 8-GPU run. Same tasks, arithmetic and slab layout as force_sym with rect == 1, without the triangular task
+// list and the diagonal tasks of the square case.
+template <class M, int W, bool EQ>
+__device__ __forceinline__ void force_sym_rect_t(const SymParamsT<typename M::V4, typename M::S>& p, typename M::V4* const sh,
+                                                 const typename M::S m0)
+{
+    constexpr int BPL = M::BPL;
+    constexpr int B = 64 * W * BPL;
+    constexpr int NCH = B / 64;
+    using V4 = typename M::V4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int task = p.task0 + (int)blockIdx.x;
+    const int I = task % p.nbi, J = task / p.nbi;
+    const V4* const xi = p.x + p.i0;
+    M t;
+    t.set_eps2(p.eps2);
+    const int ibase = I * B + w * (64 * BPL) + lane;
+#pragma unroll
+    for (int k = 0; k < BPL; ++k) {
+        const int i = ibase + k * 64;
+        t.set(k, i < p.ni ? xi[i] : pad4<V4, EQ>());
+    }
+    const int rot = ((lane + 16) & 63) << 2;
+    const int jbase = J * B + lane;
+    auto fetch = [&](int c) {
+        const int j = jbase + c * 64;
+        int ja = p.j0 + j;
+        if (p.wrap && ja >= p.wrap) ja -= p.wrap;
+        return j < p.nj ? p.x[ja] : pad4<V4, EQ>();
+    };
+#pragma unroll
+    for (int r = 0; r < BPL; ++r) sh[r * (64 * W) + tid] = zero4<V4>();
+    __syncthreads();
+    int c = w * BPL;
+    V4 nxt = fetch(c);
+    for (int q = 0; q < NCH; ++q) {
+        V4 bj = nxt;
+        const int cn = (c + 1 == NCH) ? 0 : c + 1;
+        if (q + 1 < NCH) nxt = fetch(cn);
+        V4 aj = sh[c * 64 + lane];
+        for (int ph = 0; ph < 4; ++ph) {
+            sym_row_pass<true, EQ>(t, bj, aj);
+            bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot);
+            if (!EQ) bj.w = next_row(bj.w, rot);
+            aj.x = next_row(aj.x, rot); aj.y = next_row(aj.y, rot); aj.z = next_row(aj.z, rot);
+        }
+        sh[c * 64 + lane] = aj;
+        __syncthreads();
+        c = cn;
+    }
+    V4* const out_j = p.slabs_j + (size_t)I * p.stride_j;
+    for (int e = tid; e < B; e += 64 * W) {
+        const int j = J * B + e;
+        if (j < p.nj) {
+            V4 a = sh[e];
+            if (EQ) { a.x *= m0; a.y *= m0; a.z *= m0; }
+            a.w = 0;
+            out_j[j] = a;
+        }
+    }
+    if (EQ) t.scale(m0);
+    V4* const out_i = p.slabs_i + (size_t)J * p.stride_i;
+#pragma unroll
+    for (int k = 0; k < BPL; ++k) {
+        const int i = ibase + k * 64;
+        if (i < p.ni) out_i[i] = t.acc(k);
+    }
+}
+
+template <class M, int W>
+__global__ void __launch_bounds__(64 * W, 1) force_sym_rect(const SymParamsT<typename M::V4, typename M::S> p)
+{
+    __shared__ typename M::V4 sh[64 * W * M::BPL];
+    double m0 = 0.0;
+    if (eq_uniform(p.eqm, p.eq_gen, &m0)) force_sym_rect_t<M, W, true>(p, sh, (typename M::S)m0);
+    else force_sym_rect_t<M, W, false>(p, sh, (typename M::S)m0);
+}
+
 // The same kernel compiled for EXACTLY WPS waves per SIMD (amdgpu_waves_per_eu). Measured alternative, tools/symbench.hip only: it does
 // not change the register allocation (200 VGPRs either way) and is within noise of the plain build (profiles/r03_symbench_rows_262144.txt).
 template <class M, int W, int WPS>

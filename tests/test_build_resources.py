@@ -89,6 +89,13 @@ def test_square_only_kernels_keep_the_occupancy_of_the_general_ones(nb, kernels)
         assert r["LDS Size"] == 64 * 4 * bpl * 16
 
 
+def test_rectangular_only_kernel(kernels):
+    """nbody_accel_cross's build of the (4,10) shape: at least the two waves per SIMD the cost model counts on, LDS for three
+    workgroups per CU."""
+    r = _get(kernels, "nbk::force_sym_rect<nbk::SymPacked<10>, 4>")
+    assert r["Occupancy"] >= 2 and r["LDS Size"] == 64 * 4 * 10 * 16 and r["AGPRs"] == 0, r
+
+
 @pytest.mark.parametrize("bpl", [2, 4, 8, 10])
 def test_balanced_run_kernels_fit_two_waves_per_simd(kernels, bpl):
     """The balanced-run plan puts exactly two workers on every SIMD (kBalWavesPerSimd): every instantiation must allow that,

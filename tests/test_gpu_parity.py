@@ -1319,24 +1319,26 @@ def test_equal_mass_cross_launch_and_whole_steps(nb, oracle):
     x = torch.from_numpy(x0).cuda()
     i0, i1, j0, cnt = 10000, 30000, 50000, 19000                 # sources 50000..59999, 0..8999
     src = np.r_[np.arange(j0, n), np.arange(0, j0 + cnt - n)]
-    res = {}
-    for mode in (-1, 0):
-        ctx = nb.engine.Context()
-        ctx.set_equal_mass(mode)
-        ai = torch.zeros((i1 - i0, 4), device="cuda")
-        aj = torch.zeros((cnt, 4), device="cuda")
-        ctx.accel_cross(x, ai, i0, i1, False, j0, cnt, aj)
-        ctx.sync()
-        res[mode] = (ai.cpu().numpy(), aj.cpu().numpy())
-        if mode == -1:
-            assert ctx.equal_mass_verdict()["uniform"]
     xs = np.concatenate([x0[i0:i1], x0[src]])
     ti = oracle.accel_range(xs, 0, 256, i1 - i0, len(xs), eps2=0.002, f64acc=True)
     tj = oracle.accel_range(xs, i1 - i0 + cnt - 256, i1 - i0 + cnt, 0, i1 - i0, eps2=0.002, f64acc=True)
-    for mode in (-1, 0):
-        assert np.abs(res[mode][0][:256] - ti)[:, :3].max() / np.abs(ti[:, :3]).max() <= 1e-5
-        assert np.abs(res[mode][1][-256:] - tj)[:, :3].max() / np.abs(tj[:, :3]).max() <= 1e-5
-    assert not np.array_equal(res[-1][0], res[0][0])             # 1/60000 is not a power of two: the roundings differ
+    for shape in ((0, 0), (4, 10), (4, 8)):                      # (4,10): the rectangular-only build of the kernel; (4,8): the general one
+        res = {}
+        for mode in (-1, 0):
+            ctx = nb.engine.Context()
+            ctx.set_equal_mass(mode)
+            ctx.set_symmetric_shape(*shape)
+            ai = torch.zeros((i1 - i0, 4), device="cuda")
+            aj = torch.zeros((cnt, 4), device="cuda")
+            ctx.accel_cross(x, ai, i0, i1, False, j0, cnt, aj)
+            ctx.sync()
+            res[mode] = (ai.cpu().numpy(), aj.cpu().numpy())
+            if mode == -1:
+                assert ctx.equal_mass_verdict()["uniform"]
+        for mode in (-1, 0):
+            assert np.abs(res[mode][0][:256] - ti)[:, :3].max() / np.abs(ti[:, :3]).max() <= 1e-5, shape
+            assert np.abs(res[mode][1][-256:] - tj)[:, :3].max() / np.abs(tj[:, :3]).max() <= 1e-5, shape
+        assert not np.array_equal(res[-1][0], res[0][0])         # 1/60000 is not a power of two: the roundings differ
     x1 = x0.copy(); x1[3, 3] *= 2                                # a heavier body inside the wrapped part of the source run
     xh = torch.from_numpy(x1).cuda()
     out = {}

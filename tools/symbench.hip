@@ -295,6 +295,33 @@ int main(int argc, char** argv)
     };
     printf("N=%d %s  one-sided vs fp64 truth: %.3g of max|a|\n", n, plummer ? "plummer" : "cube", err_vs_truth(a_ref));
 
+    if (getenv("SYMBENCH_RECT")) {   // A/B of the rectangular launch (two disjoint halves of the system, as nbody_accel_cross issues it)
+        const int h = n / 2, B = 2560;
+        const int nbi = (h + B - 1) / B, nbj = (n - h + B - 1) / B;
+        float4* xs;
+        CK(hipMalloc(&xs, ((size_t)nbj * h + (size_t)nbi * (n - h)) * 16));
+        nbk::MassInfo* di;
+        CK(hipMalloc(&di, sizeof(nbk::MassInfo)));
+        CK(hipMemset(di, 0, sizeof(nbk::MassInfo)));
+        nbk::MassScanParams mp{};
+        mp.x = dx; mp.i0 = 0; mp.ni = n; mp.out = di; mp.gen = 1;
+        nbk::mass_scan<float4><<<1024, 256>>>(mp);
+        for (int eq = 0; eq < 2; ++eq) {
+            nbk::SymParams sp{};
+            sp.x = dx; sp.slabs_i = xs; sp.slabs_j = xs + (size_t)nbj * h; sp.ni = h; sp.nj = n - h; sp.i0 = 0; sp.j0 = h; sp.wrap = n;
+            sp.nbi = nbi; sp.nbj = nbj; sp.stride_i = h; sp.stride_j = n - h; sp.rect = 1; sp.eps2 = eps2;
+            if (eq) { sp.eqm = di; sp.eq_gen = 1; }
+            const int grid = nbi * nbj;
+            for (int rep = 0; rep < 2; ++rep) {
+                const float tg = median_ms([&] { nbk::force_sym<nbk::SymPacked<10>, 4><<<grid, 256>>>(sp); }, reps);
+                const float tr = median_ms([&] { nbk::force_sym_rect<nbk::SymPacked<10>, 4><<<grid, 256>>>(sp); }, reps);
+                printf("rect %d x %d blocks (%d tasks), %s path: general kernel %.3f ms, rect-only kernel %.3f ms\n", nbi, nbj, grid,
+                       eq ? "equal-mass" : "general", tg, tr);
+            }
+        }
+        CK(hipDeviceSynchronize());
+        return 0;
+    }
     std::vector<SymVariant> vars;
     nbk::MassInfo* dinfo;
     CK(hipMalloc(&dinfo, sizeof(nbk::MassInfo)));
