@@ -621,9 +621,18 @@ def main():
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
     if multi:
+        # The line is out. Tear-down (shard, communicator, process group) has nothing left to prove: if it has not finished within a
+        # minute — a peer that is already gone, a proxy thread that does not join — the process ends itself with the exit code it has
+        # earned instead of leaving the launcher waiting.
+        import threading
+        sys.stdout.flush()
+        watchdog = threading.Timer(60.0, lambda: os._exit(0))
+        watchdog.daemon = True
+        watchdog.start()
         dist.barrier()
         sim.close()
         dist.destroy_process_group()
+        watchdog.cancel()
 
 
 if __name__ == "__main__":
