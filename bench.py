@@ -559,6 +559,10 @@ def main():
         "ms_per_step_min": min(repeats) / args.steps * 1e3,
         "ms_per_step_max": max(repeats) / args.steps * 1e3,
         "per_gpu_value": value / world,
+        # which pair arithmetic the timed steps ran (decided on the device from the masses), and the other one beside it
+        **({"equal_mass_path": equal_mass["path_taken"]} if equal_mass else {}),
+        **({"general_path_value": equal_mass["general_path"]["value"], "general_path_ms_per_step": equal_mass["general_path"]["ms_per_step"]}
+           if equal_mass and equal_mass.get("general_path") else {}),
         **({"single_gpu_same_n": same_n} if same_n else {}),
         "config": {
             "workload": f"all-pairs gravity step, N={n} bodies, {'fp64' if f64 else 'fp32'}, {'Plummer' if args.init == 1 else 'reference-cube'} init seed 12345, "
