@@ -1425,3 +1425,39 @@ def test_equal_mass_path_in_double(nb, oracle):
             assert not ctx.equal_mass_verdict()["uniform"]
         res[mode] = a.cpu().numpy()
     assert np.array_equal(res[-1], res[0])
+
+
+def test_equal_mass_api_corners(nb, oracle):
+    """Mode range, the verdict before any scan and below the scan's minimum size, a stream change between launches of the balanced
+    runs (the inbox clear is re-issued on the new stream), and the verdict after a run of the fused small-N step (no scan there)."""
+    ctx = nb.engine.Context()
+    for bad in (-2, 2, 7):
+        with pytest.raises(nb.NBodyError):
+            ctx.set_equal_mass(bad)
+    assert ctx.equal_mass_verdict() == {"scanned": False, "uniform": False, "mass": 0.0}
+    n = 3000                                                     # below 4096 bodies no scan is launched, whatever the kernel
+    x0 = nb.engine.seeded_bodies(n, 1, 1)
+    sim = nb.engine.Simulation(x0, dt=0.01, eps2=0.002, kernel=nb.KERNEL_SYMMETRIC)
+    sim.run(2)
+    assert not sim.ctx.equal_mass_verdict()["scanned"]
+    sim = nb.engine.Simulation(nb.engine.seeded_bodies(8192, 1, 1), dt=0.01, eps2=0.002)   # fused step: one-sided arithmetic, no scan
+    sim.run(3)
+    assert sim.ctx.step_info(8192)["fused"] and not sim.ctx.equal_mass_verdict()["scanned"]
+    n = 12000                                                    # balanced runs on two streams in turn
+    x0 = nb.engine.seeded_bodies(n, 1, 2)
+    x = torch.from_numpy(x0).cuda()
+    ref, _ = _accel_all(nb, x0, -1)
+    ctx = nb.engine.Context()
+    assert ctx.step_info(n)["balanced"]
+    a = torch.zeros((n, 4), device="cuda")
+    ctx.accel_range(x, a, 0, n, 0, n)
+    ctx.sync()
+    side = torch.cuda.Stream()
+    ctx.set_stream(side)
+    a2 = torch.zeros((n, 4), device="cuda")
+    side.wait_stream(torch.cuda.current_stream())
+    ctx.accel_range(x, a2, 0, n, 0, n)
+    ctx.sync()
+    ctx.set_stream(None)
+    assert np.array_equal(a.cpu().numpy(), ref) and np.array_equal(a2.cpu().numpy(), ref)
+    assert ctx.equal_mass_verdict()["uniform"]
