@@ -230,7 +230,16 @@ int nbody_shard_create(nbody_shard** out, nbody_ctx* ctx, int rank, int world, i
     if (int rc = alloc(&s->a, p.shard)) return cleanup(rc);
     if (int rc = alloc(&s->jbuf, p.jbuf_bodies)) return cleanup(rc);
     if (int rc = alloc(&s->rbuf, p.rbuf_bodies)) return cleanup(rc);
-    hipError_t e = hipStreamCreateWithFlags(&s->comm, hipStreamNonBlocking);
+    // The communication stream gets the highest priority the device offers: its few workgroups (RCCL's channels) must be placed
+    // as soon as a slot frees up, not behind the thousands of queued force workgroups they are meant to run beside.
+    int prio_least = 0, prio_greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&s->comm, hipStreamNonBlocking, prio_greatest);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        s->comm = nullptr;
+        e = hipStreamCreateWithFlags(&s->comm, hipStreamNonBlocking);
+    }
     if (e != hipSuccess) return cleanup(nbody_fail(NBODY_ERR_HIP, "hipStreamCreateWithFlags failed: %s", hipGetErrorString(e)));
     for (hipEvent_t* ev : {&s->ev_integrated, &s->ev_gathered, &s->ev_cross, &s->ev_exchanged})
         if (int rc = new_event(ev, false)) return cleanup(rc);
