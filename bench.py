@@ -287,7 +287,12 @@ def main():
             os.environ.setdefault("WORLD_SIZE", "1")
         limit = datetime.timedelta(minutes=5)   # a collective that never completes becomes an error, not a hang
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, timeout=limit)
+            opts = None
+            try:    # RCCL's kernels on a high-priority stream: placed as soon as a slot frees, not behind the queued force workgroups
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            except Exception:
+                opts = None
+            dist.init_process_group("nccl", device_id=dev, timeout=limit, **({"pg_options": opts} if opts is not None else {}))
         else:
             dist.init_process_group(args.backend, timeout=limit)
 
