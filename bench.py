@@ -376,6 +376,12 @@ def main():
 
     if args.equal_mass == "off":
         ctx.set_equal_mass(0)
+    steps_done = [0]          # every step this process asks for (the fp64 line compares with an fp32 run of the same length)
+    _run_steps = run
+
+    def run(k):
+        steps_done[0] += k
+        _run_steps(k)
 
     def barrier():
         sync()
@@ -477,28 +483,26 @@ def main():
     # Equal masses (a Plummer sphere: every body 1/N) let the symmetric kernels factor the common mass out of the pair sums; the
     # decision is taken on the device per launch. Say whether the timed steps took that path, and time the GENERAL path (what a
     # system with unequal masses, e.g. the reference's own initial conditions, gets) on the same bodies right here.
-    equal_mass = None
-    if True:
-        v = ctx.equal_mass_verdict()
-        equal_mass = {"path_taken": bool(v["scanned"] and v["uniform"]), "decided": "on the device, per launch (nbk::mass_scan); nbody_ctx_set_equal_mass(0) or --equal-mass off disables it",
-                      "masses": ("all equal: %.9g" % v["mass"]) if v["scanned"] and v["uniform"] else "not all equal (or never scanned): general pair arithmetic"}
-        # (a collective decision: every rank times the general path or none does)
-        equal_mass["path_taken_on_every_rank"] = max_over_ranks(0.0 if equal_mass["path_taken"] else 1.0) == 0.0
-        if equal_mass["path_taken_on_every_rank"] and not args.no_general_path:
-            ctx.set_equal_mass(0)
-            run(2)
-            gen = []
-            for _ in range(3):
-                barrier()
-                t0 = time.perf_counter()
-                run(args.steps)
-                barrier()
-                gen.append(max_over_ranks(time.perf_counter() - t0))
-            ctx.set_equal_mass(-1)
-            g = statistics.median(gen)
-            equal_mass["general_path"] = {"ms_per_step": g / args.steps * 1e3, "value": float(n) * n * args.steps / g, "unit": "pairs/s",
-                                          "frac_of_peak_at_20_flop": FLOP_PER_PAIR * float(n) * n * args.steps / g / 1e12 / ((FP64_VECTOR_PEAK_TFLOPS if f64 else FP32_VECTOR_PEAK_TFLOPS) * world),
-                                          "repeats": 3, "note": "same bodies, same run, equal-mass path switched off: what unequal masses get"}
+    v = ctx.equal_mass_verdict()
+    equal_mass = {"path_taken": bool(v["scanned"] and v["uniform"]), "decided": "on the device, per launch (nbk::mass_scan); nbody_ctx_set_equal_mass(0) or --equal-mass off disables it",
+                  "masses": ("all equal: %.9g" % v["mass"]) if v["scanned"] and v["uniform"] else "not all equal (or never scanned): general pair arithmetic"}
+    # (a collective decision: every rank times the general path or none does)
+    equal_mass["path_taken_on_every_rank"] = max_over_ranks(0.0 if equal_mass["path_taken"] else 1.0) == 0.0
+    if equal_mass["path_taken_on_every_rank"] and not args.no_general_path:
+        ctx.set_equal_mass(0)
+        run(2)
+        gen = []
+        for _ in range(3):
+            barrier()
+            t0 = time.perf_counter()
+            run(args.steps)
+            barrier()
+            gen.append(max_over_ranks(time.perf_counter() - t0))
+        ctx.set_equal_mass(-1)
+        g = statistics.median(gen)
+        equal_mass["general_path"] = {"ms_per_step": g / args.steps * 1e3, "value": float(n) * n * args.steps / g, "unit": "pairs/s",
+                                      "frac_of_peak_at_20_flop": FLOP_PER_PAIR * float(n) * n * args.steps / g / 1e12 / ((FP64_VECTOR_PEAK_TFLOPS if f64 else FP32_VECTOR_PEAK_TFLOPS) * world),
+                                      "repeats": 3, "note": "same bodies, same run, equal-mass path switched off: what unequal masses get"}
 
     elapsed = statistics.median(repeats)
     pairs_step = float(n) * n
@@ -537,7 +541,7 @@ def main():
     fp_diff = None
     if f64:
         # configs[4]'s tolerance check: the fp32 engine from the same start, same number of steps
-        total_steps = args.warmup + args.steps * len(repeats)
+        total_steps = steps_done[0]
         s32 = nbody_amd.engine.Simulation(x0, dt=args.dt, eps2=args.eps2, device=dev.index)
         s32.run(total_steps)
         x32 = s32.state()[0].astype(np.float64)
