@@ -219,7 +219,8 @@ def main():
     ap.add_argument("--masses", default="init", choices=["init", "random"], help="init: as the initial conditions give them (Plummer: every body 1/N, "
                     "which the symmetric kernels' equal-mass path picks up; cube: the reference's random masses); random: Plummer positions "
                     "with masses drawn uniformly over a decade, as the reference's fill_with_random4 does, total 1 - the general path")
-    ap.add_argument("--equal-mass", default="auto", choices=["auto", "off"], help="off: nbody_ctx_set_equal_mass(0), the general pair "
+    ap.add_argument("--equal-mass", default="auto", choices=["auto", "on", "off"], help="auto: the library's default (launches of 32768 bodies "
+                    "or more are scanned for one common mass); on: from 4096 bodies; off: nbody_ctx_set_equal_mass(0), the general pair "
                     "arithmetic whatever the masses")
     ap.add_argument("--no-general-path", action="store_true", help="skip the extra repeats that time the general pair arithmetic when the "
                     "timed steps took the equal-mass path (profile runs: only the timed kernels in the trace)")
@@ -374,8 +375,8 @@ def main():
         info["schedule"] = {0: "canonical", 1: "onesided", 2: "symmetric"}[plan.schedule]
         info["cross_launches"] = [[plan.launch[l].i0, plan.launch[l].i1, plan.launch[l].j0, plan.launch[l].count] for l in range(plan.n_launches)]
 
-    if args.equal_mass == "off":
-        ctx.set_equal_mass(0)
+    eq_mode = {"auto": -1, "on": 1, "off": 0}[args.equal_mass]
+    ctx.set_equal_mass(eq_mode)
     steps_done = [0]          # every step this process asks for (the fp64 line compares with an fp32 run of the same length)
     _run_steps = run
 
@@ -498,7 +499,7 @@ def main():
             run(args.steps)
             barrier()
             gen.append(max_over_ranks(time.perf_counter() - t0))
-        ctx.set_equal_mass(-1)
+        ctx.set_equal_mass(eq_mode)
         g = statistics.median(gen)
         equal_mass["general_path"] = {"ms_per_step": g / args.steps * 1e3, "value": float(n) * n * args.steps / g, "unit": "pairs/s",
                                       "frac_of_peak_at_20_flop": FLOP_PER_PAIR * float(n) * n * args.steps / g / 1e12 / ((FP64_VECTOR_PEAK_TFLOPS if f64 else FP32_VECTOR_PEAK_TFLOPS) * world),

@@ -158,9 +158,12 @@ int nbody_ctx_set_fused(nbody_ctx* ctx, int mode);
  * their term underflows to exactly 0) and the force kernel reads its verdict — no host round trip, nothing to declare. Bodies
  * that are not uniform (the reference's own initial conditions: masses random in [1e8, 1e9]) take the general path, bit for bit
  * as before. Same tolerances on either path; the two differ by rounding (m0 * sum(w r) against sum((m0 w) r)), each is bitwise
- * reproducible run to run. mode -1 / 1 (default): as described, for launches of 4096 bodies or more of the symmetric kernels
- * (block pairs, unit runs, balanced runs, nbody_accel_cross); 0: never. nbody_step scans once per call (the integrate carries
- * the masses through unchanged; about 3 us), and not at all under graph replay. */
+ * reproducible run to run. The scan is a dependent launch of its own, about 3 us per nbody_step call (once per call: the integrate
+ * carries the masses through unchanged) or accel launch; never under graph replay. mode -1 (default): launches of 32768 bodies or
+ * more of the symmetric kernels (block pairs, unit runs, balanced runs, nbody_accel_cross; for the latter both ranges count) — a
+ * caller that steps ONE step per call, as the reference's loop does, would otherwise pay the scan every step: 4-8 % of a step at
+ * 9216 ... 16384 bodies, whatever the masses are; mode 1: launches of 4096 bodies or more (for callers who queue many steps per
+ * call, or know their masses are equal: +4 ... 6 % from 8193 to 32767 bodies); 0: never. */
 int nbody_ctx_set_equal_mass(nbody_ctx* ctx, int mode);
 
 /* What the last scan found (synchronises the context's stream): *scanned 0 = no scan has run yet; *uniform 1 = the bodies of the

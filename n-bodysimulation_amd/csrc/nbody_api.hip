@@ -108,7 +108,8 @@ struct nbody_ctx {
     nbk::MassInfo* eqm = nullptr;  // two verdict slots of nbk::mass_scan: [0] square launches / whole steps, [1] cross launches
     unsigned int eq_gen = 0;   // generation of the last scan
     int eq_last_slot = 0;      // slot the last scan wrote
-    int eq_mode = -1;          // equal-mass path of the symmetric kernels: -1 / 1 where the device-side scan finds one common mass, 0 never
+    int eq_mode = -1;          // equal-mass path of the symmetric kernels where the device-side scan finds one common mass: -1 launches of
+                               // kEqAutoMinBodies bodies or more, 1 of kEqMinBodies or more, 0 never
     void* xslabs = nullptr;    // workspace of nbody_accel_cross (its own, so that a square evaluation issued in parts
     size_t xslab_bytes = 0;    // around cross launches keeps its partial sums)
     bool legacy_eps = false;     // strict kernel evaluates `+ EPS2` as the older snapshot does
@@ -625,14 +626,18 @@ int ensure_inbox(nbody_ctx* c, const BalShape& b)
 // Equal-mass path: scans the bodies of the coming launch(es) on the stream (x[i0 .. i0+ni) and, when nj > 0, the run of nj bodies
 // from j0, wrapping at `wrap`) and hands out the verdict slot and this scan's generation. No host round trip: the force kernel
 // reads the verdict itself. *q stays nullptr when the path is switched off (or the verdict slots cannot be allocated).
-constexpr int kEqMinBodies = 4096;   // below this the scan launch costs more than the path saves
+constexpr int kEqMinBodies = 4096;       // mode 1: below this the scan launch costs more than the path saves even over many steps
+constexpr int kEqAutoMinBodies = 32768;  // mode -1 (default): the scan is a dependent launch of its own (about 3 us per call). A caller that
+                                         // steps one step per call — the reference's own loop, main.cpp:146-156 — pays it every step: 1.5 % of a
+                                         // 190-us step at 32768 bodies, but 4-8 % at 9216 ... 16384, whatever the masses are. The automatic
+                                         // mode therefore leaves smaller launches alone; mode 1 is for callers who know better.
 
 template <class V4>
 int eq_scan(nbody_ctx* c, int slot, const V4* x, int i0, int ni, int j0, int nj, int wrap, const nbk::MassInfo** q, unsigned int* gen)
 {
     *q = nullptr;
     *gen = 0;
-    if (c->eq_mode == 0 || ni <= 0 || ni + nj < kEqMinBodies) return NBODY_OK;
+    if (c->eq_mode == 0 || ni <= 0 || ni + nj < (c->eq_mode == 1 ? kEqMinBodies : kEqAutoMinBodies)) return NBODY_OK;
     if (!c->eqm) {
         if (hipMalloc(reinterpret_cast<void**>(&c->eqm), 2 * sizeof(nbk::MassInfo)) != hipSuccess) {
             (void)hipGetLastError();
@@ -995,7 +1000,7 @@ int nbody_ctx_set_fused(nbody_ctx* c, int mode)
 int nbody_ctx_set_equal_mass(nbody_ctx* c, int mode)
 {
     if (int rc = check_ctx(c)) return rc;
-    if (mode < -1 || mode > 1) return fail(NBODY_ERR_CONFIG, "equal-mass mode must be -1 (auto), 0 (never) or 1 (wherever the scan finds one common mass)");
+    if (mode < -1 || mode > 1) return fail(NBODY_ERR_CONFIG, "equal-mass mode must be -1 (auto: launches of 32768 bodies or more), 0 (never) or 1 (launches of 4096 bodies or more)");
     c->eq_mode = mode;
     return NBODY_OK;
 }
@@ -1045,7 +1050,7 @@ int nbody_ctx_reserve(nbody_ctx* c, int n_targets)
     if (n_targets < 0) return fail(NBODY_ERR_INVALID, "n_targets < 0");
     ON_DEVICE(c);
     refresh_ws_cap(c);
-    if (c->eq_mode != 0 && !c->eqm && n_targets >= kEqMinBodies) {   // the verdict slots of the equal-mass scan, ahead of the first step
+    if (c->eq_mode != 0 && !c->eqm && n_targets >= (c->eq_mode == 1 ? kEqMinBodies : kEqAutoMinBodies) / 2) {   // the verdict slots of the equal-mass scan, ahead of the first step
         if (hipMalloc(reinterpret_cast<void**>(&c->eqm), 2 * sizeof(nbk::MassInfo)) == hipSuccess) HIP_TRY(hipMemset(c->eqm, 0, 2 * sizeof(nbk::MassInfo)));
         else { (void)hipGetLastError(); c->eqm = nullptr; }
     }

@@ -110,8 +110,8 @@ class Context:
         check(self._lib.nbody_ctx_set_fused(self._h, mode))
 
     def set_equal_mass(self, mode: int) -> None:
-        """Equal-mass path of the symmetric kernels (decided on the device, per launch): -1 / 1 wherever the scan finds one common
-        mass, 0 never."""
+        """Equal-mass path of the symmetric kernels (decided on the device, per launch, by a scan of the masses): -1 launches of
+        32768 bodies or more, 1 launches of 4096 bodies or more, 0 never."""
         check(self._lib.nbody_ctx_set_equal_mass(self._h, mode))
 
     def equal_mass_verdict(self) -> dict:

@@ -1258,7 +1258,7 @@ def test_equal_mass_path_vs_general_path(nb, oracle, n, kind):
     fp64-accumulated CPU sums at both ends of the array: the usual 1e-5; exact mass linearity; bitwise repeat."""
     x0 = nb.engine.seeded_bodies(n, 1, 2024)
     assert np.all(x0[:, 3] == x0[0, 3])
-    a_eq, ctx = _accel_all(nb, x0, -1)
+    a_eq, ctx = _accel_all(nb, x0, 1)
     info = ctx.step_info(n)
     assert info[kind] and (kind == "symmetric" or info["symmetric"]), info
     verdict = ctx.equal_mass_verdict()
@@ -1274,10 +1274,10 @@ def test_equal_mass_path_vs_general_path(nb, oracle, n, kind):
     for i0 in (0, n - 200):
         truth = oracle.accel_range(x0, i0, i0 + 200, 0, n, eps2=0.002, f64acc=True)
         assert np.abs(a_eq[i0:i0 + 200] - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 1e-5
-    again, _ = _accel_all(nb, x0, -1)
+    again, _ = _accel_all(nb, x0, 1)
     assert np.array_equal(again, a_eq)
     x4 = x0.copy(); x4[:, 3] *= 4
-    a4, _ = _accel_all(nb, x4, -1)
+    a4, _ = _accel_all(nb, x4, 1)
     assert np.array_equal(a4[:, :3], 4 * a_eq[:, :3])
 
 
@@ -1290,20 +1290,20 @@ def test_one_different_body_takes_the_general_path_bit_for_bit(nb, oracle, n):
     for where in (0, n // 2 + 1, n - 1):
         x1 = x0.copy()
         x1[where, 3] = np.nextafter(x1[where, 3], np.float32(1.0))
-        a_on, ctx = _accel_all(nb, x1, -1)
+        a_on, ctx = _accel_all(nb, x1, 1)
         v = ctx.equal_mass_verdict()
         assert v["scanned"] and not v["uniform"], (where, v)
         a_off, _ = _accel_all(nb, x1, 0)
         assert np.array_equal(a_on, a_off), where
     x2 = x0.copy()
     x2[n // 3, 0] = 3e15                                         # uniform masses, but a body the far-away padding is not far from
-    a_on, ctx = _accel_all(nb, x2, -1)
+    a_on, ctx = _accel_all(nb, x2, 1)
     assert not ctx.equal_mass_verdict()["uniform"]
     a_off, _ = _accel_all(nb, x2, 0)
     assert np.array_equal(a_on, a_off)
     x3 = x0.copy()
     x3[5, 1] = np.nan
-    a_on, ctx = _accel_all(nb, x3, -1)
+    a_on, ctx = _accel_all(nb, x3, 1)
     assert not ctx.equal_mass_verdict()["uniform"]
     a_off, _ = _accel_all(nb, x3, 0)
     assert np.array_equal(a_on, a_off, equal_nan=True)
@@ -1324,7 +1324,7 @@ def test_equal_mass_cross_launch_and_whole_steps(nb, oracle):
     tj = oracle.accel_range(xs, i1 - i0 + cnt - 256, i1 - i0 + cnt, 0, i1 - i0, eps2=0.002, f64acc=True)
     for shape in ((0, 0), (4, 10), (4, 8)):                      # (4,10): the rectangular-only build of the kernel; (4,8): the general one
         res = {}
-        for mode in (-1, 0):
+        for mode in (1, 0):
             ctx = nb.engine.Context()
             ctx.set_equal_mass(mode)
             ctx.set_symmetric_shape(*shape)
@@ -1333,16 +1333,16 @@ def test_equal_mass_cross_launch_and_whole_steps(nb, oracle):
             ctx.accel_cross(x, ai, i0, i1, False, j0, cnt, aj)
             ctx.sync()
             res[mode] = (ai.cpu().numpy(), aj.cpu().numpy())
-            if mode == -1:
+            if mode == 1:
                 assert ctx.equal_mass_verdict()["uniform"]
-        for mode in (-1, 0):
+        for mode in (1, 0):
             assert np.abs(res[mode][0][:256] - ti)[:, :3].max() / np.abs(ti[:, :3]).max() <= 1e-5, shape
             assert np.abs(res[mode][1][-256:] - tj)[:, :3].max() / np.abs(tj[:, :3]).max() <= 1e-5, shape
-        assert not np.array_equal(res[-1][0], res[0][0])         # 1/60000 is not a power of two: the roundings differ
+        assert not np.array_equal(res[1][0], res[0][0])         # 1/60000 is not a power of two: the roundings differ
     x1 = x0.copy(); x1[3, 3] *= 2                                # a heavier body inside the wrapped part of the source run
     xh = torch.from_numpy(x1).cuda()
     out = {}
-    for mode in (-1, 0):
+    for mode in (1, 0):
         ctx = nb.engine.Context()
         ctx.set_equal_mass(mode)
         ai = torch.zeros((i1 - i0, 4), device="cuda")
@@ -1350,21 +1350,21 @@ def test_equal_mass_cross_launch_and_whole_steps(nb, oracle):
         ctx.accel_cross(xh, ai, i0, i1, False, j0, cnt, aj)
         ctx.sync()
         out[mode] = (ai.cpu().numpy(), aj.cpu().numpy())
-        if mode == -1:
+        if mode == 1:
             assert not ctx.equal_mass_verdict()["uniform"]
-    assert np.array_equal(out[-1][0], out[0][0]) and np.array_equal(out[-1][1], out[0][1])
+    assert np.array_equal(out[1][0], out[0][0]) and np.array_equal(out[1][1], out[0][1])
     # whole steps
     n = 65536
     x0 = nb.engine.seeded_bodies(n, 1, 5)
     fin = {}
-    for mode in (-1, 0):
+    for mode in (1, 0):
         sim = nb.engine.Simulation(x0, dt=0.01, eps2=0.002)
         sim.ctx.set_equal_mass(mode)
         sim.run(5)
         fin[mode] = sim.state()
-        assert sim.ctx.equal_mass_verdict()["uniform"] == (mode == -1)
-    assert np.abs(fin[-1][0] - fin[0][0])[:, :3].max() <= 1e-6
-    assert np.abs(fin[-1][2] - fin[0][2])[:, :3].max() <= 3e-6 * np.abs(fin[0][2][:, :3]).max()
+        assert sim.ctx.equal_mass_verdict()["uniform"] == (mode == 1)
+    assert np.abs(fin[1][0] - fin[0][0])[:, :3].max() <= 1e-6
+    assert np.abs(fin[1][2] - fin[0][2])[:, :3].max() <= 3e-6 * np.abs(fin[0][2][:, :3]).max()
     xr = nb.engine.seeded_bodies(n, 0, 5)                        # the reference's kind of initial conditions: random masses
     sim = nb.engine.Simulation(xr, dt=0.1, eps2=0.002)
     sim.run(2)
@@ -1376,12 +1376,12 @@ def test_equal_mass_zero_and_negative_common_mass(nb, oracle):
     """A common mass of zero gives exact zeros, a negative one the mirrored field; nothing non-finite appears."""
     n = 30000
     x0 = nb.engine.seeded_bodies(n, 1, 3)
-    ref, _ = _accel_all(nb, x0, -1)
+    ref, _ = _accel_all(nb, x0, 1)
     xz = x0.copy(); xz[:, 3] = 0.0
-    az, ctx = _accel_all(nb, xz, -1)
+    az, ctx = _accel_all(nb, xz, 1)
     assert ctx.equal_mass_verdict()["uniform"] and np.all(az == 0)
     xn = x0.copy(); xn[:, 3] *= -1
-    an, _ = _accel_all(nb, xn, -1)
+    an, _ = _accel_all(nb, xn, 1)
     assert np.array_equal(an[:, :3], -ref[:, :3])
 
 
@@ -1393,7 +1393,7 @@ def test_equal_mass_path_in_double(nb, oracle):
     x0 = nb.engine.seeded_bodies(n, 1, 17).astype(np.float64)
     x0[:, 3] = 1.0 / n                                            # a double that is not a rounded float
     out = {}
-    for mode in (-1, 0):
+    for mode in (1, 0):
         ctx = nb.engine.Context()
         ctx.set_equal_mass(mode)
         x = torch.from_numpy(x0).cuda()
@@ -1403,17 +1403,17 @@ def test_equal_mass_path_in_double(nb, oracle):
         ctx.sync()
         assert ctx.step_info_f64(n)["symmetric"]
         ver = ctx.equal_mass_verdict()
-        assert ver["scanned"] == (mode == -1) and ver["uniform"] == (mode == -1)
+        assert ver["scanned"] == (mode == 1) and ver["uniform"] == (mode == 1)
         out[mode] = a.cpu().numpy()
     scale = np.abs(out[0][:, :3]).max()
-    assert np.abs(out[-1] - out[0])[:, :3].max() <= 1e-14 * scale and not np.array_equal(out[-1], out[0])
+    assert np.abs(out[1] - out[0])[:, :3].max() <= 1e-14 * scale and not np.array_equal(out[1], out[0])
     for i0 in (0, n - 128):
         want = oracle.accel_range_f64(x0, i0, i0 + 128, 0, n, eps2=0.002)
-        for mode in (-1, 0):
+        for mode in (1, 0):
             assert np.abs(out[mode][i0:i0 + 128] - want)[:, :3].max() / np.abs(want[:, :3]).max() <= 1e-12
     x1 = x0.copy(); x1[n - 1, 3] *= 1.0 + 2.0 ** -40
     res = {}
-    for mode in (-1, 0):
+    for mode in (1, 0):
         ctx = nb.engine.Context()
         ctx.set_equal_mass(mode)
         x = torch.from_numpy(x1).cuda()
@@ -1421,10 +1421,10 @@ def test_equal_mass_path_in_double(nb, oracle):
         a = torch.zeros_like(x)
         ctx.step_f64(x, a, v, dt=0.01, eps2=0.002, steps=1)
         ctx.sync()
-        if mode == -1:
+        if mode == 1:
             assert not ctx.equal_mass_verdict()["uniform"]
         res[mode] = a.cpu().numpy()
-    assert np.array_equal(res[-1], res[0])
+    assert np.array_equal(res[1], res[0])
 
 
 def test_equal_mass_api_corners(nb, oracle):
@@ -1435,19 +1435,25 @@ def test_equal_mass_api_corners(nb, oracle):
         with pytest.raises(nb.NBodyError):
             ctx.set_equal_mass(bad)
     assert ctx.equal_mass_verdict() == {"scanned": False, "uniform": False, "mass": 0.0}
-    n = 3000                                                     # below 4096 bodies no scan is launched, whatever the kernel
+    n = 3000                                                     # below 4096 bodies no scan is launched, whatever the mode
     x0 = nb.engine.seeded_bodies(n, 1, 1)
     sim = nb.engine.Simulation(x0, dt=0.01, eps2=0.002, kernel=nb.KERNEL_SYMMETRIC)
+    sim.ctx.set_equal_mass(1)
     sim.run(2)
     assert not sim.ctx.equal_mass_verdict()["scanned"]
+    for n, scans in ((20000, False), (32768, True)):             # the automatic mode leaves launches below 32768 bodies alone
+        sim = nb.engine.Simulation(nb.engine.seeded_bodies(n, 1, 1), dt=0.01, eps2=0.002)
+        sim.run(1)
+        assert sim.ctx.step_info(n)["symmetric"] and sim.ctx.equal_mass_verdict()["scanned"] == scans, n
     sim = nb.engine.Simulation(nb.engine.seeded_bodies(8192, 1, 1), dt=0.01, eps2=0.002)   # fused step: one-sided arithmetic, no scan
     sim.run(3)
     assert sim.ctx.step_info(8192)["fused"] and not sim.ctx.equal_mass_verdict()["scanned"]
     n = 12000                                                    # balanced runs on two streams in turn
     x0 = nb.engine.seeded_bodies(n, 1, 2)
     x = torch.from_numpy(x0).cuda()
-    ref, _ = _accel_all(nb, x0, -1)
+    ref, _ = _accel_all(nb, x0, 1)
     ctx = nb.engine.Context()
+    ctx.set_equal_mass(1)
     assert ctx.step_info(n)["balanced"]
     a = torch.zeros((n, 4), device="cuda")
     ctx.accel_range(x, a, 0, n, 0, n)
