@@ -466,6 +466,17 @@ struct SymPacked {
 #pragma unroll
         for (int k = 0; k < H; ++k) { ax[k] = ax[k] * v; ay[k] = ay[k] * v; az[k] = az[k] * v; }
     }
+    __device__ __forceinline__ float mass0() const { return m[0][0]; }
+    // do all of this lane's stationary bodies carry exactly the mass m0?
+    __device__ __forceinline__ bool masses_are(const float m0) const
+    {
+        const unsigned int b = __builtin_bit_cast(unsigned int, m0);
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < H; ++k)
+            ok = ok && __builtin_bit_cast(unsigned int, (float)m[k][0]) == b && __builtin_bit_cast(unsigned int, (float)m[k][1]) == b;
+        return ok;
+    }
     // all BPL stationary bodies against the moving body s; t = sum_k (m_k w_k) r_k when SYM.
     // EQ: every body of the launch has the same mass (MassInfo below): a_i += w r, t += w r — the two mass multiplies per pair
     // (and the moving body's mass itself) drop out, the common mass is applied once per stored sum. 14 instead of 16 packed ops
@@ -899,6 +910,131 @@ __global__ void __launch_bounds__(64 * W, 1) force_sym_square(const SymParamsT<t
     double m0 = 0.0;
     if (eq_uniform(p.eqm, p.eq_gen, &m0)) force_sym_square_t<M, W, true>(p, sh, (typename M::S)m0);
     else force_sym_square_t<M, W, false>(p, sh, (typename M::S)m0);
+}
+
+// MEASURED ALTERNATIVE, not shipped (tools/symbench.hip with SYMBENCH_EQ=1, profiles/r03_symbench_local_decision_262144.txt): the
+// equal-mass decision taken LOCALLY, per wave and per 64-body chunk, from the masses the wave holds and loads anyway — no scan launch,
+// no verdict slot, no far-away padding. Equal to the scan-based kernel on equal masses (10.31-10.36 vs 10.24-10.33 ms per launch at
+// N = 262144, one box) but 1 % SLOWER on unequal ones (11.36-11.38 vs 11.21-11.28: 242 VGPRs and another schedule of the rotation
+// pass) — and unequal masses are what the reference's own initial conditions have. The scan costs 3 us per call; it stays. A wave whose stationary bodies all carry m0 (finite,
+// of ordinary magnitude) accumulates its I-side sums in units of m0; a chunk that carries m0 too takes the equal-mass pass (its
+// J-side sums are brought to true units when they meet the other waves' in LDS); any other chunk takes the general pass with its
+// masses divided by m0. Padding bodies are massless as ever: their chunk (or their wave) simply is not uniform.
+__device__ __forceinline__ bool wave_all(const bool ok) { return __builtin_amdgcn_ballot_w64(ok) == ~0ull; }
+
+template <bool SYM, class M>
+__device__ __forceinline__ void sym_chunk(M& t, typename M::V4 bj, typename M::V4& aj, const int rot, const bool eq)
+{
+    if (eq) {
+        for (int ph = 0; ph < 4; ++ph) {
+            sym_row_pass<SYM, true>(t, bj, aj);
+            bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot);
+            if (SYM) { aj.x = next_row(aj.x, rot); aj.y = next_row(aj.y, rot); aj.z = next_row(aj.z, rot); }
+        }
+    } else {
+        for (int ph = 0; ph < 4; ++ph) {
+            sym_row_pass<SYM, false>(t, bj, aj);
+            bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot); bj.w = next_row(bj.w, rot);
+            if (SYM) { aj.x = next_row(aj.x, rot); aj.y = next_row(aj.y, rot); aj.z = next_row(aj.z, rot); }
+        }
+    }
+}
+
+template <class M, int W>
+__global__ void __launch_bounds__(64 * W, 1) force_sym_square_local(const SymParamsT<typename M::V4, typename M::S> p, const int allow_eq)
+{
+    constexpr int BPL = M::BPL;
+    constexpr int B = 64 * W * BPL;
+    constexpr int NCH = B / 64;
+    using V4 = typename M::V4;
+    using S = typename M::S;
+    __shared__ V4 sh[B];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = p.nbi;
+    const int task = p.task0 + (int)blockIdx.x;
+    const int npair = nb * (nb - 1) / 2;
+    const bool diag = task >= npair;
+    int I, J;
+    if (diag) {
+        I = J = task - npair;
+    } else {
+        const float q = 2.0f * nb - 1.0f;
+        I = (int)((q - __builtin_sqrtf(q * q - 8.0f * (float)task)) * 0.5f);
+        if (I < 0) I = 0;
+        if (I > nb - 2) I = nb - 2;
+        while (I < nb - 2 && sym_row_offset(I + 1, nb) <= task) ++I;
+        while (I > 0 && sym_row_offset(I, nb) > task) --I;
+        J = I + 1 + (task - sym_row_offset(I, nb));
+    }
+    const V4* const x = p.x + p.i0;
+    const int n = p.ni;
+    M t;
+    t.set_eps2(p.eps2);
+    const int ibase = I * B + w * (64 * BPL) + lane;
+#pragma unroll
+    for (int k = 0; k < BPL; ++k) {
+        const int i = ibase + k * 64;
+        t.set(k, i < n ? x[i] : zero4<V4>());
+    }
+    // the wave's own verdict on its stationary bodies
+    S m0 = (S)0, inv_m0 = (S)0;
+    bool eqI = false;
+    if (allow_eq) {
+        m0 = __builtin_bit_cast(S, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t.mass0())));
+        const S am = m0 < 0 ? -m0 : m0;
+        eqI = wave_all(t.masses_are(m0)) && am >= (S)1e-30 && am <= (S)1e30;
+        inv_m0 = eqI ? (S)1 / m0 : (S)0;
+    }
+    const int rot = ((lane + 16) & 63) << 2;
+    const int jbase = J * B + lane;
+    auto fetch = [&](int c) {
+        const int j = jbase + c * 64;
+        return j < n ? x[j] : zero4<V4>();
+    };
+    if (!diag) {
+#pragma unroll
+        for (int r = 0; r < BPL; ++r) sh[r * (64 * W) + tid] = zero4<V4>();
+        __syncthreads();
+    }
+    int c = w * BPL;
+    V4 nxt = fetch(c);
+    for (int q = 0; q < NCH; ++q) {
+        V4 bj = nxt;
+        const int cn = (c + 1 == NCH) ? 0 : c + 1;
+        if (q + 1 < NCH) nxt = fetch(cn);
+        const bool eqJ = eqI && wave_all(same_bits(bj.w, m0));
+        if (eqI && !eqJ) bj.w *= inv_m0;                    // this chunk's masses in units of m0, like the sums they go into
+        if (diag) {
+            V4 aj = zero4<V4>();
+            sym_chunk<false>(t, bj, aj, rot, eqJ);
+        } else {
+            V4 aj = eqJ ? zero4<V4>() : sh[c * 64 + lane];
+            sym_chunk<true>(t, bj, aj, rot, eqJ);
+            if (eqJ) {
+                V4 o = sh[c * 64 + lane];
+                o.x += aj.x * m0; o.y += aj.y * m0; o.z += aj.z * m0;
+                aj = o;
+            }
+            sh[c * 64 + lane] = aj;
+            __syncthreads();
+        }
+        c = cn;
+    }
+    if (!diag) {
+        V4* const out_j = p.slabs_j + (size_t)I * p.stride_j;
+        for (int e = tid; e < B; e += 64 * W) {
+            const int j = J * B + e;
+            if (j < n) { V4 a = sh[e]; a.w = 0; out_j[j] = a; }
+        }
+    }
+    if (eqI) t.scale(m0);
+    V4* const out_i = p.slabs_i + (size_t)J * p.stride_i;
+#pragma unroll
+    for (int k = 0; k < BPL; ++k) {
+        const int i = ibase + k * 64;
+        if (i < n) out_i[i] = t.acc(k);
+    }
 }
 
 // The RECTANGULAR case alone (two disjoint ranges, rect == 1; the J run may wrap): what nbody_accel_cross launches — seven eighths of a

@@ -329,6 +329,8 @@ int main(int argc, char** argv)
     unsigned eq_gen = 0;
     if (getenv("SYMBENCH_EQ")) {   // A/B of the equal-mass path (same kernels, verdict pointer null or set), interleaved
         for (int rep = 0; rep < 2; ++rep) {
+            vars.push_back({"sym bpl10 w4 SQUARE LOCAL decision, off", 2560, [](const nbk::SymParams& p, int grid) { nbk::force_sym_square_local<nbk::SymPacked<10>, 4><<<grid, 256>>>(p, 0); }});
+            vars.push_back({"sym bpl10 w4 SQUARE LOCAL decision, on", 2560, [](const nbk::SymParams& p, int grid) { nbk::force_sym_square_local<nbk::SymPacked<10>, 4><<<grid, 256>>>(p, 1); }});
             vars.push_back({"sym bpl10 w4 SQUARE general path", 2560, [](const nbk::SymParams& p, int grid) { nbk::force_sym_square<nbk::SymPacked<10>, 4><<<grid, 256>>>(p); }});
             vars.push_back({"sym bpl10 w4 SQUARE equal-mass", 2560, [](const nbk::SymParams& p, int grid) { nbk::force_sym_square<nbk::SymPacked<10>, 4><<<grid, 256>>>(p); }, true});
             vars.push_back(sym_variant<nbk::SymPacked<10>, 4>("sym bpl10 w4 general kernel, general path"));
