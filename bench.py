@@ -602,6 +602,8 @@ def main():
             "peak": peak,
             "unit": "TFLOP/s",
             "frac": achieved / peak,
+            # BASELINE.md 3 asks for the 78.6 TF line too: the fp32 vector rate without packed (two-per-lane) instructions
+            **({"frac_of_unpacked_fp32_peak_78_6_tf": achieved / 78.6} if not f64 else {}),
             "traffic": traffic,
             **({"traffic_source": traffic_source} if traffic_source else {}),
             **({"traffic_note": traffic_note} if traffic_note else {}),
