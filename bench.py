@@ -634,6 +634,10 @@ def main():
     }
     if rank == 0:
         if cpu is not None:
+            if cpu.get("value"):      # the GPU / CPU ratios, for the serial reference build and for the all-core restatement
+                cpu["gpu_over_cpu"] = value / cpu["value"]
+                if cpu.get("port_all_cores_value"):
+                    cpu["gpu_over_cpu_all_cores"] = value / cpu["port_all_cores_value"]
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
     if multi:
