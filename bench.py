@@ -53,6 +53,50 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+PHASE = ["start"]                # what this rank is doing (named by the stall dump and by the tear-down watchdog)
+
+
+def phase(name: str) -> None:
+    PHASE[0] = name
+
+
+def arm_stall_dump() -> None:
+    """NBODY_BENCH_STACKS_AFTER=<seconds>: a run still alive after that long writes its phase and all its Python stacks to
+    stderr (the multi-rank tests set it just below their own deadline, so a stall locates itself)."""
+    after = os.environ.get("NBODY_BENCH_STACKS_AFTER")
+    if not after:
+        return
+    import faulthandler
+    import threading
+
+    def say():
+        print(f"[bench.py rank {os.environ.get('RANK', '0')} pid {os.getpid()}] still running after {after} s in phase: {PHASE[0]}",
+              file=sys.stderr, flush=True)
+    t = threading.Timer(float(after), say)
+    t.daemon = True
+    t.start()
+    faulthandler.dump_traceback_later(float(after) + 1.0, repeat=False, file=sys.stderr)
+
+
+def kfd_queue_census():
+    """How many hardware queues this process holds on the GPU (KFD's sysfs view), by type — diagnostic for ranks that SHARE one
+    GPU: past the device's hardware queue slots the scheduler time-slices run lists, and a spinning RCCL kernel then waits whole
+    slices for its peer."""
+    base = f"/sys/class/kfd/kfd/proc/{os.getpid()}/queues"
+    try:
+        out = {"total": 0}
+        for q in os.listdir(base):
+            try:
+                t = open(os.path.join(base, q, "type")).read().strip()
+            except OSError:
+                t = "?"
+            out["total"] += 1
+            out["type_" + t] = out.get("type_" + t, 0) + 1
+        return out
+    except OSError as e:
+        return {"error": type(e).__name__}
+
+
 FLOP_PER_PAIR = 20.0             # SURVEY.md 8(a) a2 / 8(d): the agreed algorithmic count
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
 FP64_VECTOR_PEAK_TFLOPS = 78.6
@@ -232,12 +276,18 @@ def main():
     ap.add_argument("--comm", default="torch", choices=["torch", "native"], help="who runs the step's two collectives: torch = "
                     "torch.distributed on the --backend group; native = the library's own RCCL communicator (nbody_comm_rccl_*), "
                     "its unique id broadcast through the --backend group, which then only carries barriers and reductions")
+    ap.add_argument("--comm-priority", default="auto", choices=["auto", "high", "normal"], help="priority of the communication stream(s): high = "
+                    "the device's greatest (RCCL's few workgroups are placed as soon as a slot frees, not behind the queued force workgroups), "
+                    "normal; auto = high when every rank has a GPU of its own, normal when ranks share one (--fake-hosts / gloo rehearsals: every "
+                    "priority level is one more hardware queue per process)")
+    ap.add_argument("--no-single-gpu-point", action="store_true", help="multi-GPU runs: skip rank 0's same-N single-GPU timing before the sharded phase")
     ap.add_argument("--fake-hosts", action="store_true", help="rehearsal only: give every rank its own NCCL_HOSTID so that RCCL "
                     "accepts several ranks on ONE GPU (it then talks over its socket transport on the loopback interface)")
     ap.add_argument("--force-sharded", action="store_true", help="take the multi-GPU code path (process group, census, sharded step, "
                     "checks) even with ONE rank — what a 1-GPU box can exercise of it over real RCCL")
     ap.add_argument("--no-multi-gpu-check", action="store_true", help="skip the in-run parity / cross-rank checks (world > 1)")
     args = ap.parse_args()
+    arm_stall_dump()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -262,6 +312,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     ndev = torch.cuda.device_count()
     shared_gpu = args.fake_hosts or (args.backend != "nccl" and args.comm != "native")
+    comm_priority = args.comm_priority if args.comm_priority != "auto" else ("normal" if shared_gpu and world > 1 else "high")
+    os.environ["NBODY_COMM_STREAM_PRIORITY"] = comm_priority      # read by nbody_shard_create
     if world > ndev and not shared_gpu:
         raise SystemExit(f"{world} ranks but {ndev} GPU(s): RCCL needs one GPU per rank (use --backend gloo, or --fake-hosts, to rehearse)")
     dev = torch.device("cuda", local_rank % ndev)
@@ -287,10 +339,11 @@ def main():
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
         limit = datetime.timedelta(minutes=5)   # a collective that never completes becomes an error, not a hang
+        phase("init_process_group")
         if args.backend == "nccl":
             opts = None
             try:    # RCCL's kernels on a high-priority stream: placed as soon as a slot frees, not behind the queued force workgroups
-                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True) if comm_priority == "high" else None
             except Exception:
                 opts = None
             dist.init_process_group("nccl", device_id=dev, timeout=limit, **({"pg_options": opts} if opts is not None else {}))
@@ -329,6 +382,35 @@ def main():
         if not distinct and not shared_gpu:
             raise SystemExit(f"census: {world} ranks but the devices are not distinct: {recs}")
 
+    # ---- the same-N single-GPU point of the strong-scaling series, measured in THIS run (rank 0 alone, the others wait) --------
+    same_n = None
+    if multi and world > 1 and not args.no_single_gpu_point:
+        phase("single_gpu_same_n")
+        rec = [None]
+        if rank == 0:
+            s1 = nbody_amd.engine.Simulation(x0, dt=args.dt, eps2=args.eps2, device=dev.index, **kopts)
+            if args.sym_waves or args.sym_bpl:
+                s1.ctx.set_symmetric_shape(args.sym_waves, args.sym_bpl)
+            s1.ctx.set_equal_mass({"auto": -1, "on": 1, "off": 0}[args.equal_mass])
+            k1 = max(1, min(args.steps, int(math.ceil(2.0 / (float(n) * n / 6.5e12)))))   # about 2 s of steps, at most --steps
+            s1.run(1, sync=False)
+            s1.ctx.sync()
+            t0 = time.perf_counter()
+            s1.run(k1, sync=False)
+            s1.ctx.sync()
+            t1 = time.perf_counter() - t0
+            v1 = s1.ctx.equal_mass_verdict()
+            rec[0] = {"ms_per_step": t1 / k1 * 1e3, "value": float(n) * n * k1 / t1, "unit": "pairs/s", "steps": k1, "n_bodies": n,
+                      "measured_in_this_run": True, "equal_mass_path": bool(v1["scanned"] and v1["uniform"]),
+                      "launch": {k: v for k, v in s1.ctx.step_info(n).items() if k in ("symmetric", "runs", "balanced", "fused", "block_bodies", "slabs")},
+                      "where": "rank 0's GPU, plain nbody_step of all N bodies, before the sharded phase" +
+                               (" (the other ranks of this rehearsal share that GPU but are idle in a barrier)" if shared_gpu else "")}
+            s1.ctx.close()
+            del s1
+            torch.cuda.empty_cache()
+        dist.broadcast_object_list(rec, src=0)
+        same_n = rec[0]
+
     if f64:
         class _F64Sim:   # same alloc/init/H2D sequence as engine.Simulation, double state
             def __init__(self):
@@ -360,7 +442,7 @@ def main():
         info = ctx.step_info(n)
     else:
         sim = nbody_amd.sharded.ShardedSimulation(x0, dt=args.dt, eps2=args.eps2, device=dev, sym_waves=args.sym_waves,
-                                                  sym_bpl=args.sym_bpl, comm=args.comm, **kopts)
+                                                  sym_bpl=args.sym_bpl, comm=args.comm, comm_priority=comm_priority, **kopts)
         ctx = sim.ctx
         run = sim.step
         sync = sim.sync
@@ -391,43 +473,59 @@ def main():
             dist.barrier()
 
     # ---- multi-GPU self-check, part 1: one sharded step against the single-GPU kernel -------------------------------------
+    # twice: on Plummer positions with masses drawn over a decade (the cross launches and the exchange then carry MASS-WEIGHTED
+    # J-side sums, what the reference's own initial conditions give), and on the bench's own bodies (which the run continues from)
     check = None
     steps_before_timing = args.warmup
     if multi and not args.no_multi_gpu_check:
-        run(1)                       # accelerations at the initial positions, through the whole sharded machinery
-        barrier()
-        steps_before_timing = max(args.warmup - 1, 0)
+        phase("multi_gpu_check")
         ref_ctx = nbody_amd.engine.Context(device=dev.index, dt=args.dt, eps2=args.eps2, kernel=nbody_amd.KERNEL_ONESIDED)
-        xfull = torch.zeros((sim.n_pad, 4), dtype=torch.float32, device=dev)
-        xfull[:n] = torch.from_numpy(x0).to(dev)
-        if sim.n_pad > n:            # the shard's padding bodies: massless, on top of body 0
-            xfull[n:] = xfull[0]
-            xfull[n:, 3] = 0.0
-        samples = min(4096, sim.shard)
-        pieces = 4 if samples >= 1024 else 1
-        per = samples // pieces
-        worst, amax = 0.0, 0.0
-        for k in range(pieces):      # sample ranges spread over the own block
-            off = (sim.shard - per) * k // max(pieces - 1, 1)
-            i0 = sim.i0 + off
-            ref = torch.empty((per, 4), dtype=torch.float32, device=dev)
-            ref_ctx.accel_range(xfull, ref, i0, i0 + per, 0, sim.n_pad)
-            ref_ctx.sync()
-            got = sim.a[off:off + per]
-            worst = max(worst, float((got - ref)[:, :3].abs().max().item()))
-            amax = max(amax, float(ref[:, :3].abs().max().item()))
+
+        def one_step_against_single_gpu(bodies):
+            sim.reset(bodies)
+            run(1)                   # accelerations at the initial positions, through the whole sharded machinery
+            barrier()
+            xfull = torch.zeros((sim.n_pad, 4), dtype=torch.float32, device=dev)
+            xfull[:n] = torch.from_numpy(bodies).to(dev)
+            if sim.n_pad > n:        # the shard's padding bodies: massless, on top of body 0
+                xfull[n:] = xfull[0]
+                xfull[n:, 3] = 0.0
+            samples = min(4096, sim.shard)
+            pieces = 4 if samples >= 1024 else 1
+            per = samples // pieces
+            worst, amax = 0.0, 0.0
+            for k in range(pieces):  # sample ranges spread over the own block
+                off = (sim.shard - per) * k // max(pieces - 1, 1)
+                i0 = sim.i0 + off
+                ref = torch.empty((per, 4), dtype=torch.float32, device=dev)
+                ref_ctx.accel_range(xfull, ref, i0, i0 + per, 0, sim.n_pad)
+                ref_ctx.sync()
+                got = sim.a[off:off + per]
+                worst = max(worst, float((got - ref)[:, :3].abs().max().item()))
+                amax = max(amax, float(ref[:, :3].abs().max().item()))
+            del xfull
+            rel = worst / amax if amax > 0 else float("inf")
+            rel_all = max_over_ranks(rel)
+            finite = max_over_ranks(0.0 if bool(torch.isfinite(sim.a).all().item()) else 1.0) == 0.0
+            return rel_all, finite, per * pieces
+
+        xr = x0.copy()
+        u = np.random.RandomState(777).uniform(1.0, 10.0, n)
+        xr[:, 3] = (u / u.sum() * float(x0[:, 3].astype(np.float64).sum())).astype(np.float32)     # same total mass, one decade of spread
+        rel_rand, finite_rand, _ = one_step_against_single_gpu(xr)
+        rel_all, finite, sampled = one_step_against_single_gpu(x0)
         ref_ctx.close()
-        del xfull
-        rel = worst / amax if amax > 0 else float("inf")
-        rel_all = max_over_ranks(rel)
-        finite = max_over_ranks(0.0 if bool(torch.isfinite(sim.a).all().item()) else 1.0) == 0.0
-        check = {"sampled_bodies_per_rank": per * pieces, "reference": "single-GPU one-sided kernel (nbody_accel_range) over all sources, on every rank's own GPU",
-                 "max_rel_da": rel_all, "tolerance": 5e-5, "finite": finite}
-        if not (rel_all <= 5e-5 and finite):
+        steps_before_timing = max(args.warmup - 1, 0)
+        check = {"sampled_bodies_per_rank": sampled, "reference": "single-GPU one-sided kernel (nbody_accel_range) over all sources, on every rank's own GPU",
+                 "max_rel_da": rel_all, "tolerance": 5e-5, "finite": finite,
+                 "random_masses": {"max_rel_da": rel_rand, "finite": finite_rand,
+                                   "bodies": "the same positions, masses uniform over a decade (seed 777): mass-weighted J-side sums through the cross launches and the exchange"}}
+        if not (rel_all <= 5e-5 and finite and rel_rand <= 5e-5 and finite_rand):
             if rank == 0:
                 print(json.dumps({"error": "multi_gpu_check failed", "multi_gpu_check": check, "rccl": rccl}), flush=True)
             raise SystemExit(3)
 
+    phase("warmup")
     run(steps_before_timing)
     barrier()
 
@@ -446,6 +544,7 @@ def main():
             raise SystemExit(3)
         barrier()
 
+    phase("timed repeats")
     if multi:
         sim.comm_timing(True)
     # The force kernel's own time comes from a pair of HIP events around every launch. At the sizes the metric is quoted on that costs
@@ -480,6 +579,11 @@ def main():
             kernel_launches += launches
     ctx.timing(False)
     comm = sim.comm_report() if multi else None
+    if multi:   # hardware queues every rank holds on its GPU by now (ranks that share one GPU compete for its queue slots)
+        qs = [None] * world
+        dist.all_gather_object(qs, {"rank": rank, "pid": os.getpid(), **kfd_queue_census()})
+        rccl["kfd_queues"] = sorted(qs, key=lambda r: r["rank"])
+        rccl["comm_priority"] = comm_priority
 
     # Equal masses (a Plummer sphere: every body 1/N) let the symmetric kernels factor the common mass out of the pair sums; the
     # decision is taken on the device per launch. Say whether the timed steps took that path, and time the GENERAL path (what a
@@ -490,19 +594,33 @@ def main():
     # (a collective decision: every rank times the general path or none does)
     equal_mass["path_taken_on_every_rank"] = max_over_ranks(0.0 if equal_mass["path_taken"] else 1.0) == 0.0
     if equal_mass["path_taken_on_every_rank"] and not args.no_general_path:
+        phase("general_path")
         ctx.set_equal_mass(0)
         run(2)
-        gen = []
+        gen, gen_kernel_ms = [], []
+        if inline_events:
+            ctx.timing(True)
+            barrier()
+            ctx.timing_read()
         for _ in range(3):
             barrier()
             t0 = time.perf_counter()
             run(args.steps)
             barrier()
             gen.append(max_over_ranks(time.perf_counter() - t0))
+            gen_kernel_ms.append(ctx.timing_read()[0] if inline_events else 0.0)
+        ctx.timing(False)
         ctx.set_equal_mass(eq_mode)
         g = statistics.median(gen)
+        # force-kernel seconds per step by HIP events (this rank); small systems run un-instrumented: the whole step stands in
+        gk = statistics.median(gen_kernel_ms) * 1e-3 / args.steps if inline_events else g / args.steps
+        pk = FP64_VECTOR_PEAK_TFLOPS if f64 else FP32_VECTOR_PEAK_TFLOPS
+        rp = float(sim.shard) * sim.n_pad if multi else float(n) * n
         equal_mass["general_path"] = {"ms_per_step": g / args.steps * 1e3, "value": float(n) * n * args.steps / g, "unit": "pairs/s",
-                                      "frac_of_peak_at_20_flop": FLOP_PER_PAIR * float(n) * n * args.steps / g / 1e12 / ((FP64_VECTOR_PEAK_TFLOPS if f64 else FP32_VECTOR_PEAK_TFLOPS) * world),
+                                      "kernel_ms_per_step": gk * 1e3,
+                                      "frac_of_peak_at_20_flop": FLOP_PER_PAIR * rp / gk / 1e12 / pk if gk > 0 else None,
+                                      "frac_source": "force kernel's HIP-event time, as roofline.frac" if inline_events else "whole-step wall time (no per-launch events at this size)",
+                                      "frac_of_peak_whole_step": FLOP_PER_PAIR * float(n) * n * args.steps / g / 1e12 / (pk * world),
                                       "repeats": 3, "note": "same bodies, same run, equal-mass path switched off: what unequal masses get"}
 
     elapsed = statistics.median(repeats)
@@ -528,16 +646,6 @@ def main():
                 traffic_source = "OFFLINE PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc.sh), kept in profiles/traffic.json for this launch shape; NOT measured in this run"
         except Exception:
             traffic = None
-
-    same_n = None
-    spath = os.path.join(ROOT, "profiles", "single_gpu_reference.json")
-    if multi and os.path.exists(spath):
-        try:
-            ref = json.load(open(spath)).get(str(n))
-            if ref:
-                same_n = dict(ref, measured_in_this_run=False)
-        except Exception:
-            same_n = None
 
     fp_diff = None
     if f64:
@@ -602,6 +710,14 @@ def main():
             "peak": peak,
             "unit": "TFLOP/s",
             "frac": achieved / peak,
+            # which pair arithmetic `frac` was measured on, and the GENERAL path (what unequal masses, e.g. the reference's own
+            # fill_with_random4 bodies, get) of the same run beside it: the >= 70 % target is to be read on the general path
+            "frac_path": ("equal-mass path (the bench's Plummer bodies all carry 1/N): 20 FLOP x N^2 interactions applied; the kernel executes 14 instead of "
+                          "16 packed ops per two pair evaluations" if equal_mass and equal_mass["path_taken"] else "general pair arithmetic"),
+            **({"frac_general_path": equal_mass["general_path"]["frac_of_peak_at_20_flop"], "general_path_kernel_ms_per_step": equal_mass["general_path"].get("kernel_ms_per_step"),
+                "frac_general_path_source": equal_mass["general_path"]["frac_source"]}
+               if equal_mass and equal_mass.get("general_path") else
+               {"frac_general_path": achieved / peak} if not (equal_mass and equal_mass["path_taken"]) else {}),
             # BASELINE.md 3 asks for the 78.6 TF line too: the fp32 vector rate without packed (two-per-lane) instructions
             **({"frac_of_unpacked_fp32_peak_78_6_tf": achieved / 78.6} if not f64 else {}),
             "traffic": traffic,
@@ -641,16 +757,25 @@ def main():
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
     if multi:
-        # The line is out. Tear-down (shard, communicator, process group) has nothing left to prove: if it has not finished within a
-        # minute — a peer that is already gone, a proxy thread that does not join — the process ends itself with the exit code it has
-        # earned instead of leaving the launcher waiting.
+        # The line is out. Tear-down (shard, communicator, process group): if it has not finished within a minute the process says where
+        # it hangs (phase + all Python stacks on stderr) and ends itself with a NON-ZERO exit code instead of leaving the launcher waiting.
+        import faulthandler
         import threading
         sys.stdout.flush()
-        watchdog = threading.Timer(60.0, lambda: os._exit(0))
+
+        def give_up():   # NOT a success: the line stands, but a tear-down that hangs is a defect and the exit code says so
+            print(f"[bench.py rank {rank} pid {os.getpid()}] tear-down did not finish within 60 s; hung in: {PHASE[0]}", file=sys.stderr, flush=True)
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+            sys.stderr.flush()
+            os._exit(3)
+        watchdog = threading.Timer(60.0, give_up)
         watchdog.daemon = True
         watchdog.start()
-        dist.barrier()
+        phase("teardown: barrier")
+        barrier()
+        phase("teardown: sim.close")
         sim.close()
+        phase("teardown: destroy_process_group")
         dist.destroy_process_group()
         watchdog.cancel()
 

@@ -357,6 +357,11 @@ int nbody_shard_sync(nbody_shard* shard);
  * behind the first half of the own-block pass; mean exchange time and the part of it not hidden behind the second
  * half. Any out pointer may be NULL. */
 int nbody_shard_comm_timing(nbody_shard* shard, int enable);
+/* Priority of the rank's communication stream: 1 = the greatest the device offers (the default: RCCL's few channel
+ * workgroups are placed as soon as a slot frees, not behind thousands of queued force workgroups), 0 = normal. Every
+ * priority level in use is one more hardware queue of the process, so ranks that SHARE one GPU (rehearsals) may want 0.
+ * Synchronises both streams and replaces the stream; call it between steps. */
+int nbody_shard_set_comm_priority(nbody_shard* shard, int high);
 int nbody_shard_comm_report(nbody_shard* shard, int* steps, double* gather_ms, double* gather_exposed_ms, double* exchange_ms,
                             double* exchange_exposed_ms);
 

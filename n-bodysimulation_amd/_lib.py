@@ -110,6 +110,7 @@ _SIGNATURES = {
     "nbody_shard_step_phase": (C.c_int, [_p, C.c_int]),
     "nbody_shard_sync": (C.c_int, [_p]),
     "nbody_shard_comm_timing": (C.c_int, [_p, C.c_int]),
+    "nbody_shard_set_comm_priority": (C.c_int, [_p, C.c_int]),
     "nbody_shard_comm_report": (C.c_int, [_p, C.POINTER(C.c_int)] + [C.POINTER(C.c_double)] * 4),
     "nbody_ctx_timing": (C.c_int, [_p, C.c_int]),
     "nbody_ctx_timing_read": (C.c_int, [_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),

@@ -63,6 +63,7 @@ struct nbody_shard {
     int device = 0;
     hipStream_t compute = nullptr;  // the context's launch stream
     hipStream_t comm = nullptr;     // own
+    bool comm_high = true;
     nbody_comm cb{};
     bool have_comm = false;
     nbody_shard_plan_t plan{};
@@ -95,6 +96,30 @@ int check_shard(const nbody_shard* s)
 
 nbody_float4* nb(float4* p) { return reinterpret_cast<nbody_float4*>(p); }
 
+// The communication stream gets the highest priority the device offers unless asked otherwise: its few workgroups (RCCL's
+// channels) must be placed as soon as a slot frees up, not behind the thousands of queued force workgroups they run beside.
+int make_comm_stream(nbody_shard* s, bool high)
+{
+    hipStream_t st = nullptr;
+    hipError_t e = hipErrorUnknown;
+    if (high) {
+        int prio_least = 0, prio_greatest = 0;
+        e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio_greatest);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            st = nullptr;
+        }
+    }
+    if (!st) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e != hipSuccess) return nbody_fail(NBODY_ERR_HIP, "hipStreamCreateWithFlags failed: %s", hipGetErrorString(e));
+    s->comm = st;
+    s->comm_high = high;
+    return NBODY_OK;
+}
+
+int ensure_comm(nbody_shard* s) { return s->comm ? NBODY_OK : make_comm_stream(s, s->comm_high); }
+
 int phase_gather(nbody_shard* s)
 {
     const nbody_shard_plan_t& p = s->plan;
@@ -106,6 +131,7 @@ int phase_gather(nbody_shard* s)
         s->timed.push_back(ev);
     }
     if (p.world == 1 || s->fresh) return NBODY_OK;
+    if (int rc = ensure_comm(s)) return rc;
     HIP_TRY(hipStreamWaitEvent(s->comm, s->ev_integrated, 0));  // the own block was advanced by the last integrate
     if (s->timing) HIP_TRY(hipEventRecord(s->timed.back().g0, s->comm));
     if (s->cb.all_gather(s->cb.user, nb(s->x), p.shard, static_cast<void*>(s->comm)) != 0)
@@ -158,6 +184,7 @@ int phase_exchange(nbody_shard* s)
 {
     const nbody_shard_plan_t& p = s->plan;
     if (p.world == 1 || p.schedule != NBODY_SCHEDULE_SYMMETRIC || p.shard == 0) return NBODY_OK;
+    if (int rc = ensure_comm(s)) return rc;
     HIP_TRY(hipStreamWaitEvent(s->comm, s->ev_cross, 0));
     if (s->timing) HIP_TRY(hipEventRecord(s->timed.back().x0, s->comm));
     if (s->cb.exchange(s->cb.user, p.send, p.n_sends, nb(s->jbuf), p.recv, p.n_recvs, nb(s->rbuf), static_cast<void*>(s->comm)) != 0)
@@ -230,20 +257,10 @@ int nbody_shard_create(nbody_shard** out, nbody_ctx* ctx, int rank, int world, i
     if (int rc = alloc(&s->a, p.shard)) return cleanup(rc);
     if (int rc = alloc(&s->jbuf, p.jbuf_bodies)) return cleanup(rc);
     if (int rc = alloc(&s->rbuf, p.rbuf_bodies)) return cleanup(rc);
-    // The communication stream gets the highest priority the device offers: its few workgroups (RCCL's channels) must be placed
-    // as soon as a slot frees up, not behind the thousands of queued force workgroups they are meant to run beside.
-    int prio_least = 0, prio_greatest = 0;
-    hipError_t e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&s->comm, hipStreamNonBlocking, prio_greatest);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        s->comm = nullptr;
-        e = hipStreamCreateWithFlags(&s->comm, hipStreamNonBlocking);
-    }
-    if (e != hipSuccess) return cleanup(nbody_fail(NBODY_ERR_HIP, "hipStreamCreateWithFlags failed: %s", hipGetErrorString(e)));
+    // (the communication stream is made on first use: nbody_shard_set_comm_priority may still choose its priority)
     for (hipEvent_t* ev : {&s->ev_integrated, &s->ev_gathered, &s->ev_cross, &s->ev_exchanged})
         if (int rc = new_event(ev, false)) return cleanup(rc);
-    e = hipDeviceSynchronize();  // the zero fills above ran on the null stream
+    hipError_t e = hipDeviceSynchronize();  // the zero fills above ran on the null stream
     if (e != hipSuccess) return cleanup(nbody_fail(NBODY_ERR_HIP, "hipDeviceSynchronize failed: %s", hipGetErrorString(e)));
     // size the context's slab workspace once, for the largest launch of this rank
     if (p.shard > 0)
@@ -297,7 +314,7 @@ int nbody_shard_upload(nbody_shard* s, const nbody_float4* h_bodies)
     if (p.n_total > 0 && !h_bodies) return nbody_fail(NBODY_ERR_INVALID, "null host pointer");
     DeviceScope scope(s->device);
     HIP_TRY(hipStreamSynchronize(s->compute));
-    HIP_TRY(hipStreamSynchronize(s->comm));
+    if (s->comm) HIP_TRY(hipStreamSynchronize(s->comm));
     std::vector<nbody_float4> padded((size_t)p.n_pad);
     if (p.n_total > 0) std::memcpy(padded.data(), h_bodies, (size_t)p.n_total * sizeof(nbody_float4));
     for (int i = p.n_total; i < p.n_pad; ++i) {  // massless, on top of body 0: adds exactly +-0 to every sum
@@ -321,7 +338,7 @@ int nbody_shard_upload_velocity(nbody_shard* s, const nbody_float4* h_velocity)
     if (p.n_total > 0 && !h_velocity) return nbody_fail(NBODY_ERR_INVALID, "null host pointer");
     DeviceScope scope(s->device);
     HIP_TRY(hipStreamSynchronize(s->compute));
-    HIP_TRY(hipStreamSynchronize(s->comm));
+    if (s->comm) HIP_TRY(hipStreamSynchronize(s->comm));
     if (p.shard == 0) return NBODY_OK;
     std::vector<nbody_float4> own((size_t)p.shard, nbody_float4{0, 0, 0, 0});  // padding bodies stay at rest
     for (int i = p.i0; i < p.i1 && i < p.n_total; ++i) own[(size_t)(i - p.i0)] = h_velocity[i];
@@ -335,7 +352,7 @@ int nbody_shard_download(nbody_shard* s, nbody_float4* h_x_own, nbody_float4* h_
     const nbody_shard_plan_t& p = s->plan;
     DeviceScope scope(s->device);
     HIP_TRY(hipStreamSynchronize(s->compute));
-    HIP_TRY(hipStreamSynchronize(s->comm));
+    if (s->comm) HIP_TRY(hipStreamSynchronize(s->comm));
     const size_t bytes = (size_t)p.shard * sizeof(float4);
     if (bytes == 0) return NBODY_OK;
     if (h_x_own) HIP_TRY(hipMemcpy(h_x_own, s->x + p.i0, bytes, hipMemcpyDeviceToHost));
@@ -376,7 +393,7 @@ int nbody_shard_sync(nbody_shard* s)
     if (int rc = check_shard(s)) return rc;
     DeviceScope scope(s->device);
     HIP_TRY(hipStreamSynchronize(s->compute));
-    HIP_TRY(hipStreamSynchronize(s->comm));
+    if (s->comm) HIP_TRY(hipStreamSynchronize(s->comm));
     return NBODY_OK;
 }
 
@@ -389,6 +406,25 @@ int nbody_shard_comm_timing(nbody_shard* s, int enable)
             if (ev) (void)hipEventDestroy(ev);
     s->timed.clear();
     s->timing = enable != 0;
+    return NBODY_OK;
+}
+
+int nbody_shard_set_comm_priority(nbody_shard* s, int high)
+{
+    if (int rc = check_shard(s)) return rc;
+    if (int rc = nbody_shard_sync(s)) return rc;
+    if ((high != 0) == s->comm_high) return NBODY_OK;
+    s->comm_high = high != 0;
+    if (!s->comm) return NBODY_OK;          // not made yet: the first use makes it with the new priority
+    DeviceScope scope(s->device);
+    hipStream_t old = s->comm;
+    s->comm = nullptr;
+    if (int rc = make_comm_stream(s, high != 0)) {
+        s->comm = old;
+        s->comm_high = !s->comm_high;
+        return rc;
+    }
+    (void)hipStreamDestroy(old);
     return NBODY_OK;
 }
 

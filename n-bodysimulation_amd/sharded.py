@@ -148,9 +148,11 @@ class ShardedSimulation:
 
     def __init__(self, bodies: np.ndarray, dt: float = _lib.DEFAULT_DT, eps2: float = _lib.DEFAULT_EPS2,
                  group=None, kernel: int = KERNEL_FAST, device: Optional[torch.device] = None, spatial_sort: bool = False,
-                 comm=None, **kernel_opts):
+                 comm=None, comm_priority: Optional[str] = None, **kernel_opts):
         """comm: None or "torch" = the two collectives over torch.distributed (TorchComm; RCCL when the group's backend
-        is nccl); "native" = the library's own RCCL communicator (NativeComm); or a ready TorchComm / NativeComm."""
+        is nccl); "native" = the library's own RCCL communicator (NativeComm); or a ready TorchComm / NativeComm.
+        comm_priority: "high" (the library's default) or "normal" — the priority of the rank's communication stream
+        (nbody_shard_set_comm_priority; "normal" suits ranks that share one GPU)."""
         from .engine import Context
         bodies = np.ascontiguousarray(bodies, np.float32)
         if bodies.ndim != 2 or bodies.shape[1] != 4:
@@ -196,7 +198,21 @@ class ShardedSimulation:
         self.a = wrap(ptrs[2], self.shard)
         self._jbuf = wrap(ptrs[3], self.plan.jbuf_bodies)
         self._rbuf = wrap(ptrs[4], self.plan.rbuf_bodies)
+        if comm_priority is not None:
+            if comm_priority not in ("high", "normal"):
+                raise ValueError("comm_priority must be 'high' or 'normal'")
+            check(self._lib.nbody_shard_set_comm_priority(self._h, 1 if comm_priority == "high" else 0))
         check(self._lib.nbody_shard_upload(self._h, C.c_void_p(bodies.ctypes.data)))
+
+    def reset(self, bodies: np.ndarray) -> None:
+        """New bodies (same count) for every rank, at rest: nbody_shard_upload again (synchronous; every rank calls it
+        with the same array). The next step skips the all-gather, as the first one did."""
+        bodies = np.ascontiguousarray(bodies, np.float32)
+        if bodies.shape != (self.n, 4):
+            raise ValueError(f"expected ({self.n},4) bodies")
+        if self.perm is not None:
+            bodies = np.ascontiguousarray(bodies[self.perm])
+        self._check(self._lib.nbody_shard_upload(self._h, C.c_void_p(bodies.ctypes.data)))
 
     # -- the two collectives, called by the library with the communication stream to enqueue on -----------
     def _on_all_gather(self, user, d_x_full, bodies_per_rank, stream):

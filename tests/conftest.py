@@ -12,6 +12,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "rehearsal: several RCCL ranks sharing ONE GPU (fake host ids, loopback sockets); collected last")
+
+
+def pytest_collection_modifyitems(config, items):
+    """Rehearsals on borrowed terms go LAST, whatever the file order: with -x a flake there can never leave an oracle
+    comparison or a drop-in test un-run (stable sort: everything else keeps its order)."""
+    items.sort(key=lambda it: 1 if it.get_closest_marker("rehearsal") else 0)
 
 
 @pytest.fixture(scope="session")

@@ -1,24 +1,16 @@
 """The sharded step on the GPU: a 1-rank RCCL group (the only world size a 1-GPU box allows), and
 the 2- and 3-block decomposition driven by hand on one device (same C-ABI calls a rank makes)."""
 import os
-import socket
 
 import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
 
+from _ranks import check_multi_gpu_line, free_port as _free_port, mark, run_bench, run_ranks, torchrun
 from conftest import same_bits
 
 pytestmark = pytest.mark.gpu
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
 
 
 def test_one_rank_nccl_group_equals_single_gpu(nb):
@@ -209,110 +201,31 @@ def test_native_rccl_comm_with_one_rank(nb):
         assert np.array_equal(got, want)
 
 
-class RanksStalled(Exception):
-    """The rank processes neither finished nor failed within the deadline."""
-
-
-def _guarded(worker, rank, args, q, dump_dir):
-    """Rank process body: a Python exception travels to the parent through the queue (the parent must never wait for a result
-    that cannot come), and a rank that sits in one place for two minutes writes its stacks to a file the parent can quote."""
-    import faulthandler
-    import traceback
-    f = open(os.path.join(dump_dir, f"rank{rank}.stacks"), "w")
-    faulthandler.dump_traceback_later(120, repeat=False, file=f)
-    try:
-        worker(rank, *args, q)
-    except BaseException:
-        q.put(("error", rank, traceback.format_exc()))
-        raise
-    finally:
-        faulthandler.cancel_dump_traceback_later()
-
-
-def _run_ranks(worker, world, args, deadline_s=240):
-    """Starts `world` rank processes (spawn) running worker(rank, *args, q) and returns their results sorted by rank. A rank that
-    raises fails the test with its traceback at once; a rank that dies without a word fails it with the exit code; ranks that are
-    still silent at the deadline (kept below the 7 minutes after which a GPU box takes a command for hung) are ended — exact
-    processes, the ones started here — and RanksStalled carries what their stack dumps say."""
-    import queue
-    import tempfile
-    import time
-    import torch.multiprocessing as mp
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    dump_dir = tempfile.mkdtemp(prefix="nbody_ranks_")
-    procs = [ctx.Process(target=_guarded, args=(worker, r, args, q, dump_dir)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res, t0, problem = [], time.time(), None
-    while len(res) < world and problem is None:
-        try:
-            item = q.get(timeout=1.0)
-            if item[0] == "error":
-                problem = f"rank {item[1]} raised:\n{item[2]}"
-            else:
-                res.append(item)
-        except queue.Empty:
-            dead = [(r, p.exitcode) for r, p in enumerate(procs) if p.exitcode not in (None, 0)]
-            if dead:
-                problem = f"rank process(es) died without a result: {dead}"
-            elif time.time() - t0 > deadline_s:
-                problem = "stalled"
-    if problem is None:
-        # every rank has delivered: what is left is tear-down (process group, RCCL proxy threads, interpreter exit). A rank that
-        # lingers there is ended and reported as a warning — the results it delivered stand.
-        import warnings
-        t1 = time.time()
-        for p in procs:
-            p.join(max(1.0, 45.0 - (time.time() - t1)))
-        late = [(r, p.exitcode) for r, p in enumerate(procs) if p.exitcode != 0]
-        for p in procs:
-            if p.is_alive():
-                p.terminate()
-                p.join(10)
-                if p.is_alive():
-                    p.kill()
-                    p.join(10)
-        if late:
-            warnings.warn(f"rank process(es) did not exit cleanly after delivering their results (exit codes before being ended): {late}")
-    if problem is not None:
-        for p in procs:
-            if p.is_alive():
-                p.terminate()
-        for p in procs:
-            p.join(10)
-            if p.is_alive():
-                p.kill()
-                p.join(10)
-        stacks = ""
-        for r in range(world):
-            try:
-                stacks += f"--- rank {r}\n" + open(os.path.join(dump_dir, f"rank{r}.stacks")).read()[-1500:]
-            except OSError:
-                pass
-        if problem == "stalled":
-            raise RanksStalled(f"{len(res)} of {world} ranks reported within {deadline_s} s\n{stacks}")
-        raise AssertionError(problem + "\n" + stacks)
-    return sorted(res, key=lambda t: t[0])
-
 
 def _gloo_gpu_worker(rank, world, port, n, steps, kernel, q):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    mark("init_process_group gloo")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import nbody_amd
         x0 = nbody_amd.engine.seeded_bodies(n, 1, 77)
+        mark("ShardedSimulation")
         sim = nbody_amd.sharded.ShardedSimulation(x0, dt=0.01, eps2=0.002, kernel=kernel, device=torch.device("cuda", 0),
                                                   sym_waves=1, sym_bpl=2)      # every rank on the one GPU
         sim.comm_timing(True)
+        mark(f"step({steps})")
         sim.step(steps)
+        mark("gather_state")
         x, v, a = sim.gather_state()
+        mark("comm_report")
         q.put((rank, x, v, a, sim.comm_report()))
+        mark("close")
         sim.close()
     finally:
+        mark("destroy_process_group")
         dist.destroy_process_group()
 
 
@@ -322,7 +235,7 @@ def test_sharded_simulation_multi_rank_over_gloo(nb, oracle, world, n, kernel):
     several processes; the box has one GPU, so all ranks share it and the collectives go over gloo instead of RCCL.
     kernel 3 = symmetric schedule with the exchange of J-side sums, 1 = strict (canonical order, bit-exact)."""
     steps = 3
-    res = _run_ranks(_gloo_gpu_worker, world, (world, _free_port(), n, steps, kernel))
+    res = run_ranks(_gloo_gpu_worker, world, (world, _free_port(), n, steps, kernel))
     x0 = nb.engine.seeded_bodies(n, 1, 77)
     xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
     oracle.step_jacobi(xo, ao, vo, dt=0.01, eps2=0.002, steps=steps)
@@ -343,17 +256,23 @@ def _nccl_worker(rank, world, port, n, steps, q):
     os.environ["MASTER_PORT"] = str(port)
     dev = torch.device("cuda", rank)
     torch.cuda.set_device(dev)
+    mark("init_process_group nccl")
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     try:
         import nbody_amd
         x0 = nbody_amd.engine.seeded_bodies(n, 1, 77)
+        mark("ShardedSimulation")
         sim = nbody_amd.sharded.ShardedSimulation(x0, dt=0.01, eps2=0.002, device=dev)
         sim.comm_timing(True)
+        mark(f"step({steps})")
         sim.step(steps)
+        mark("gather_state")
         x, v, a = sim.gather_state()
         q.put((rank, x, v, a, sim.comm_report()))
+        mark("close")
         sim.close()
     finally:
+        mark("destroy_process_group")
         dist.destroy_process_group()
 
 
@@ -363,7 +282,7 @@ def test_sharded_simulation_over_rccl_one_gpu_per_rank(nb, oracle):
     send/recv of the J-side sums), one process per GPU, against the CPU on sampled targets."""
     world = min(torch.cuda.device_count(), 5)     # (a GPU box admits six processes on its cards at once: this one + five ranks)
     n, steps = 65536, 2
-    res = _run_ranks(_nccl_worker, world, (world, _free_port(), n, steps), deadline_s=300)
+    res = run_ranks(_nccl_worker, world, (world, _free_port(), n, steps), deadline_s=300)
     sim = nb.engine.Simulation(nb.engine.seeded_bodies(n, 1, 77), dt=0.01, eps2=0.002)
     sim.run(steps)
     x1, v1, a1 = sim.state()
@@ -373,68 +292,15 @@ def test_sharded_simulation_over_rccl_one_gpu_per_rank(nb, oracle):
         assert np.array_equal(x, res[0][1]) and rep["steps"] == steps and rep["schedule"] == "symmetric"
 
 
-def _run_bench(args, timeout=300):
-    """bench.py (through the launcher) as a child in a session of its own; at the deadline — below the 7 minutes after which a GPU
-    box takes a silent command for hung — the whole process group started here is ended and RanksStalled raised."""
-    import json
-    import signal
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ)
-    env.pop("RANK", None), env.pop("WORLD_SIZE", None), env.pop("LOCAL_RANK", None)
-    p = subprocess.Popen([sys.executable] + args, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
-                         start_new_session=True)
-    try:
-        out, err = p.communicate(timeout=timeout)
-    except subprocess.TimeoutExpired:
-        os.killpg(p.pid, signal.SIGKILL)          # the launcher and its ranks: the session created two lines up, nothing else
-        out, err = p.communicate()
-        raise RanksStalled(f"bench.py did not finish within {timeout} s: {' '.join(args[-12:])}\n{err[-1500:]}")
-
-    class _R:
-        returncode, stdout, stderr = p.returncode, out, err
-    r = _R
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 prints ONE JSON line, the other ranks nothing
-    return json.loads(lines[0])
-
-
-def _torchrun(nproc, *bench_args):
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    return ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
-            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(nproc), *bench_args]
-
-
-def _check_multi_gpu_line(line, world, n, comm, distinct):
-    """The self-certification fields of a multi-rank bench line (bench.py docstring: census, parity, cross-rank)."""
-    assert line["n_gpus"] == world and line["scaling"] == "strong" and line["config"]["n_bodies"] == n
-    assert abs(line["per_gpu_value"] * world - line["value"]) <= 1e-6 * line["value"]
-    r = line["config"]["rccl"]
-    assert r["world"] == world and r["ranks_seen"] and r["comm"] == comm and len(r["devices"]) == world
-    assert [d["rank"] for d in r["devices"]] == list(range(world)) and r["distinct_devices"] == distinct
-    assert all("MI3" in d["name"] or "Instinct" in d["name"] or d["name"] for d in r["devices"])
-    c = line["config"]["multi_gpu_check"]
-    assert c["finite"] and c["x_bitwise_equal_across_ranks"] and 0 <= c["max_rel_da"] <= c["tolerance"] == 5e-5
-    assert c["sampled_bodies_per_rank"] >= 1024 and c["steps_checked"] >= 1
-    assert line["config"]["comm_rank0"]["steps"] >= line["steps"]
-    assert line["value"] > 1e11 and 0 < line["roofline"]["frac"] < 1 and 0 < line["roofline"]["frac_evaluated"] <= line["roofline"]["frac"]
-    # the launch description is what the own-block pass really launches: block pairs (never "runs") when it is issued in parts
-    if world > 1 and line["config"]["launch"]["schedule"] == "symmetric":
-        assert line["config"]["launch"]["symmetric"] and not line["config"]["launch"]["runs"]
-
-
 def test_bench_two_ranks_over_gloo_on_one_gpu():
     """bench.py exactly as the driver launches it for N > 1 (python -m torch.distributed.run, one process per
     rank; the launcher starts before anything touches the GPU), rehearsed with 2 ranks sharing this box's one
     GPU over gloo: one JSON line, n_gpus 2, strong scaling, the census, the in-run parity of the sharded step against the
-    single-GPU kernel, the cross-rank bitwise check and the per-step communication report."""
-    line = _run_bench(_torchrun(2, "--backend", "gloo", "--bodies", "65536", "--steps", "3", "--warmup", "2", "--repeats", "2"))
+    single-GPU kernel, the cross-rank bitwise check, the per-step communication report and the same-run single-GPU point."""
+    line = run_bench(torchrun(2, "--backend", "gloo", "--bodies", "65536", "--steps", "3", "--warmup", "2", "--repeats", "2"))
     assert line["steps"] == 3 and line["warmup"] == 2 and line["repeats"] == 2
-    _check_multi_gpu_line(line, 2, 65536, "torch", distinct=False)       # two ranks share the one GPU here
+    check_multi_gpu_line(line, 2, 65536, "torch", distinct=False)       # two ranks share the one GPU here
     assert line["config"]["rccl"]["backend"] == "gloo"
-    assert "single_gpu_same_n" not in line                               # offline figure exists for N = 1048576 only
 
 
 @pytest.mark.parametrize("comm", ["torch", "native"])
@@ -442,100 +308,9 @@ def test_bench_sharded_path_with_one_rank_over_rccl(comm):
     """The multi-GPU code path of bench.py over REAL RCCL as far as one GPU allows without tricks: one rank
     (--force-sharded): nccl process group, census (one distinct device), the sharded step through torch's RCCL ops or
     through the library's own communicator, the in-run checks."""
-    line = _run_bench(_torchrun(1, "--force-sharded", "--comm", comm, "--bodies", "65536", "--steps", "3", "--warmup", "2",
-                                "--repeats", "2"))
-    _check_multi_gpu_line(line, 1, 65536, comm, distinct=True)
+    line = run_bench(torchrun(1, "--force-sharded", "--comm", comm, "--bodies", "65536", "--steps", "3", "--warmup", "2",
+                              "--repeats", "2"))
+    check_multi_gpu_line(line, 1, 65536, comm, distinct=True)
     assert line["config"]["rccl"]["backend"] == "nccl"
     assert line["config"]["multi_gpu_check"]["max_rel_da"] < 2e-5
-
-
-def _fake_hosts_work():
-    """Can RCCL run several ranks on this box's one GPU when every rank reports its own NCCL_HOSTID (tools/rccl_hostid_probe.py)?"""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ)
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
-        env.pop(k, None)
-    import signal
-    p = subprocess.Popen([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(_free_port()), os.path.join(root, "tools", "rccl_hostid_probe.py")],
-                         cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
-    try:
-        out, err = p.communicate(timeout=240)
-    except subprocess.TimeoutExpired:
-        os.killpg(p.pid, signal.SIGKILL)          # the session started above: the launcher and its two ranks
-        out, err = p.communicate()
-        return False, "probe stalled: " + (out + err)[-1200:]
-    return p.returncode == 0, (out + err)[-1500:]
-
-
-@pytest.fixture(scope="module")
-def fake_hosts():
-    ok, log = _fake_hosts_work()
-    if not ok:
-        pytest.skip("RCCL does not accept several ranks on one GPU here, even with distinct NCCL_HOSTIDs: " + log[-300:])
-    return True
-
-
-@pytest.mark.parametrize("comm,world", [("torch", 2), ("native", 2), ("native", 3)])
-def test_bench_multi_rank_over_real_rccl_on_one_gpu(fake_hosts, comm, world):
-    """REAL multi-rank RCCL on a 1-GPU box: every rank reports its own NCCL_HOSTID, so RCCL takes them for different hosts
-    (no "Duplicate GPU") and moves the data over its socket transport on the loopback interface. Slow transport, real
-    library: ncclCommInitRank with world > 1, the in-place ncclAllGather of positions and the grouped ncclSend/ncclRecv of
-    the J-side sums run for real — through torch.distributed (comm torch) and through nbody_comm_rccl_* (comm native) —
-    and the bench line certifies itself (parity vs the single-GPU kernel, bit-identical positions on all ranks)."""
-    try:
-        line = _run_bench(_torchrun(world, "--fake-hosts", "--comm", comm, "--bodies", "49152", "--steps", "2", "--warmup", "2",
-                                    "--repeats", "2"))
-    except RanksStalled as e:   # a rehearsal on borrowed terms (see the sharded-simulation test below): a loud skip, not a pass
-        pytest.skip(f"multi-rank RCCL rehearsal on one GPU stalled ({comm}, {world} ranks): {e}")
-    _check_multi_gpu_line(line, world, 49152, comm, distinct=False)
-    r = line["config"]["rccl"]
-    assert r["backend"] == "nccl" and r["fake_hosts"]
-    assert line["config"]["comm_rank0"]["all_gather_ms_avg"] > 0 and line["config"]["comm_rank0"]["exchange_ms_avg"] > 0
-
-
-def _nccl_fake_host_worker(rank, world, port, n, steps, comm, q):
-    import sys
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    os.environ["NCCL_HOSTID"] = f"nbody-test-host-{rank}"
-    os.environ["NCCL_SOCKET_IFNAME"] = "lo"
-    os.environ["NCCL_IB_DISABLE"] = "1"
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(dev)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    try:
-        import nbody_amd
-        x0 = nbody_amd.engine.seeded_bodies(n, 1, 77)
-        sim = nbody_amd.sharded.ShardedSimulation(x0, dt=0.01, eps2=0.002, device=dev, comm=comm, sym_waves=1, sym_bpl=2)
-        sim.comm_timing(True)
-        sim.step(steps)
-        x, v, a = sim.gather_state()
-        q.put((rank, x, v, a, sim.comm_report()))
-        sim.close()
-    finally:
-        dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("comm,world,n", [("torch", 2, 6000), ("native", 2, 6000), ("native", 4, 7001), ("torch", 3, 5001)])
-def test_sharded_simulation_over_real_rccl_on_one_gpu(nb, oracle, fake_hosts, comm, world, n):
-    """The product path (ShardedSimulation -> nbody_shard_* -> RCCL) with several ranks over REAL RCCL (fake host ids, see
-    above), symmetric schedule with the exchange of J-side sums, against the CPU oracle; identical positions on every rank."""
-    steps = 3
-    try:
-        res = _run_ranks(_nccl_fake_host_worker, world, (world, _free_port(), n, steps, comm))
-    except RanksStalled as e:
-        # A rehearsal on borrowed terms (several RCCL ranks on ONE GPU, host ids faked, data over loopback sockets): a stall here
-        # has been seen once in some thirty runs and says nothing about a node with one GPU per rank. Not a pass: a loud skip.
-        pytest.skip(f"multi-rank RCCL rehearsal on one GPU stalled ({comm}, {world} ranks): {e}")
-    x0 = nb.engine.seeded_bodies(n, 1, 77)
-    xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
-    oracle.step_jacobi(xo, ao, vo, dt=0.01, eps2=0.002, steps=steps)
-    for rank, x, v, a, rep in res:
-        assert np.abs(x - xo)[:, :3].max() <= 1e-6
-        assert np.abs(a - ao)[:, :3].max() / np.abs(ao[:, :3]).max() <= 1e-5
-        assert np.array_equal(x, res[0][1]) and np.array_equal(a, res[0][3])
-        assert rep["steps"] == steps and rep["schedule"] == "symmetric"
+    assert line["value"] > 1e12            # one rank alone on the GPU: a rate floor means something here (5-6e12 expected)
