@@ -22,6 +22,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(_HERE, "liboracle.so")
 REF_SO = os.path.join(_HERE, "_ref", "libref_cpu.so")
+REF_DT001_SO = os.path.join(_HERE, "_ref", "libref_cpu_dt001.so")   # the same sources with DT 0.01f (ref_dt001.cpp)
 
 # constants.h:25-26
 REF_EPS2 = np.float32(0.002)
@@ -39,6 +40,7 @@ def build(quiet: bool = True) -> None:
 
 _lib = None
 _ref = None
+_ref_dt001 = None
 
 
 def lib() -> C.CDLL:
@@ -74,11 +76,13 @@ def have_ref() -> bool:
     return os.path.exists(REF_SO)
 
 
-def ref() -> C.CDLL:
-    """The reference's own CPU objects (C++ linkage, hence the mangled names)."""
-    global _ref
-    if _ref is None:
-        R = C.CDLL(REF_SO)
+def have_ref_dt001() -> bool:
+    return os.path.exists(REF_DT001_SO)
+
+
+def _bind_ref(path: str) -> C.CDLL:
+    if True:
+        R = C.CDLL(path)
         p = C.c_void_p
         R.CPU_compute = R._Z11CPU_computeP6float4S0_S0_i
         R.CPU_compute.argtypes = [p, p, p, C.c_int]
@@ -95,8 +99,23 @@ def ref() -> C.CDLL:
         R.verify_still_bodies = R._Z19verify_still_bodiesP6float4S0_i
         R.verify_still_bodies.argtypes = [p, p, C.c_int]
         R.verify_still_bodies.restype = None
-        _ref = R
+    return R
+
+
+def ref() -> C.CDLL:
+    """The reference's own CPU objects (C++ linkage, hence the mangled names)."""
+    global _ref
+    if _ref is None:
+        _ref = _bind_ref(REF_SO)
     return _ref
+
+
+def ref_dt001() -> C.CDLL:
+    """The reference's CPU objects compiled with DT 0.01f (oracle/ref_dt001.cpp)."""
+    global _ref_dt001
+    if _ref_dt001 is None:
+        _ref_dt001 = _bind_ref(REF_DT001_SO)
+    return _ref_dt001
 
 
 def _chk(a: np.ndarray, dtype=np.float32) -> np.ndarray:
@@ -197,6 +216,13 @@ def ref_step(X, A, V, steps=1):
     _chk(X), _chk(A), _chk(V)
     for _ in range(steps):
         ref().CPU_compute(_ptr(X), _ptr(A), _ptr(V), len(X))
+
+
+def ref_step_dt001(X, A, V, steps=1):
+    """Reference CPU_compute (validation.cpp:28-52) compiled with DT=0.01f (EPS2=0.002f as shipped)."""
+    _chk(X), _chk(A), _chk(V)
+    for _ in range(steps):
+        ref_dt001().CPU_compute(_ptr(X), _ptr(A), _ptr(V), len(X))
 
 
 def ref_pair(bi, bj, ai):

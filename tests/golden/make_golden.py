@@ -13,6 +13,12 @@ Every file holds inputs and expected outputs only (data, no reference source):
                         calls of the reference's CPU_compute. x0 itself is not stored (128 KiB): it is
                         fill_with_random4 after srand(1), which the product's generator reproduces bit
                         for bit; x0_head holds its first 8 bodies as a check.
+  ref_cpu_plummer_n1024_dt0.01.npz
+                        the BENCHMARK's time step, held by the reference build: x0 = the seeded Plummer sphere
+                        (seed 12345, the bodies of jacobi_plummer_n1024_dt0.01.npz), x/v/a after K in {1,10,100}
+                        calls of the reference's CPU_compute compiled with DT 0.01f instead of constants.h:26's
+                        0.1f (oracle/ref_dt001.cpp -> oracle/_ref/libref_cpu_dt001.so: validation.cpp compiled
+                        where it lies, the DT macro the only change; EPS2 0.002f as shipped).
   ref_pairs.npz         256 random (bi,bj,ai) triples and the reference's bodyInteractions_CPU result.
   jacobi_*.npz          outputs of OUR oracle's Jacobi step (fp32 sequential) for seeded inputs, so
                         the GPU box can check the strict kernel bit-for-bit without re-running the
@@ -60,6 +66,18 @@ def main():
     O.ref_step(x, a, v, steps=9)
     out["x_10"], out["v_10"], out["a_10"] = x.copy(), v.copy(), a.copy()
     np.savez_compressed(os.path.join(OUT, "ref_cpu_n8192.npz"), **out)
+
+    # --- the reference at the benchmark's dt (BASELINE configs[1], [2], [4]: dt = 0.01) -----------
+    assert O.have_ref_dt001(), "build oracle/_ref/libref_cpu_dt001.so first (make -C oracle)"
+    x0 = nbody_amd.engine.seeded_bodies(1024, 1, 12345)
+    out = {"x0": x0, "dt": np.float32(0.01), "eps2": np.float32(0.002)}
+    x, v, a = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
+    done = 0
+    for K in (1, 10, 100):
+        O.ref_step_dt001(x, a, v, steps=K - done)
+        done = K
+        out[f"x_{K}"], out[f"v_{K}"], out[f"a_{K}"] = x.copy(), v.copy(), a.copy()
+    np.savez_compressed(os.path.join(OUT, "ref_cpu_plummer_n1024_dt0.01.npz"), **out)
 
     rng = np.random.default_rng(2024)
     bi = (rng.uniform(-1e5, 1e5, (256, 4))).astype(np.float32)

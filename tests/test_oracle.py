@@ -48,6 +48,42 @@ def test_inplace_oracle_matches_reference_at_its_shipped_size(oracle, nb):
     assert np.array_equal(bits(a), bits(g["a_10"]))
 
 
+def test_inplace_oracle_matches_the_reference_at_the_benchmark_time_step(oracle):
+    """BASELINE configs[1], [2], [4] run dt = 0.01; the reference compiles DT 0.1f in (constants.h:26). The fixture
+    tests/golden/ref_cpu_plummer_n1024_dt0.01.npz is the REFERENCE's CPU_compute (validation.cpp:28-52, 43-49) built with
+    DT 0.01f as its only change (oracle/ref_dt001.cpp), on the seeded Plummer sphere: oracle_step_inplace(dt=0.01f)
+    reproduces it bit for bit after 1, 10 and 100 steps — so the restatement's dt is the reference's DT, not a lookalike."""
+    g = load_golden("ref_cpu_plummer_n1024_dt0.01.npz")
+    assert np.float32(g["dt"]) == np.float32(0.01) and np.float32(g["eps2"]) == oracle.REF_EPS2
+    assert np.array_equal(bits(g["x0"]), bits(load_golden("jacobi_plummer_n1024_dt0.01.npz")["x0"]))    # the same bodies as the Jacobi fixture
+    x, v, a = g["x0"].copy(), np.zeros_like(g["x0"]), np.zeros_like(g["x0"])
+    done = 0
+    for K in (1, 10, 100):
+        oracle.step_inplace(x, a, v, dt=np.float32(0.01), eps2=oracle.REF_EPS2, steps=K - done)
+        done = K
+        assert np.array_equal(bits(x), bits(g[f"x_{K}"])), f"positions differ after {K} steps"
+        assert np.array_equal(bits(v), bits(g[f"v_{K}"])), f"velocities differ after {K} steps"
+        assert np.array_equal(bits(a), bits(g[f"a_{K}"])), f"accelerations differ after {K} steps"
+    # a different dt gives different bits (the fixture does pin the time step)
+    x2, v2, a2 = g["x0"].copy(), np.zeros_like(g["x0"]), np.zeros_like(g["x0"])
+    oracle.step_inplace(x2, a2, v2, dt=oracle.REF_DT, eps2=oracle.REF_EPS2, steps=1)
+    assert not np.array_equal(bits(x2), bits(g["x_1"]))
+
+
+def test_inplace_oracle_matches_live_reference_build_at_dt001(oracle):
+    """The same against the live DT 0.01f build of the reference (oracle/_ref/libref_cpu_dt001.so) on other inputs and sizes."""
+    if not oracle.have_ref_dt001():
+        pytest.skip("oracle/_ref/libref_cpu_dt001.so not present")
+    for n, seed, K in ((1, 1, 3), (2, 2, 5), (37, 3, 7), (513, 4, 4), (1024, 5, 12)):
+        rng = np.random.default_rng(seed)
+        x0 = rng.normal(0, 1, (n, 4)).astype(np.float32)
+        x0[:, 3] = rng.uniform(0.1, 1.0, n).astype(np.float32) / n
+        r = _run(oracle.ref_step_dt001, x0, K)
+        o = _run(oracle.step_inplace, x0, K, dt=np.float32(0.01), eps2=oracle.REF_EPS2)
+        for i in range(3):
+            assert np.array_equal(bits(r[i]), bits(o[i])), (n, K, i)
+
+
 def test_pair_matches_golden_reference_pairs(oracle):
     g = load_golden("ref_pairs.npz")
     for k in range(len(g["bi"])):
