@@ -78,25 +78,6 @@ def arm_stall_dump() -> None:
     faulthandler.dump_traceback_later(float(after) + 1.0, repeat=False, file=sys.stderr)
 
 
-def kfd_queue_census():
-    """How many hardware queues this process holds on the GPU (KFD's sysfs view), by type — diagnostic for ranks that SHARE one
-    GPU: past the device's hardware queue slots the scheduler time-slices run lists, and a spinning RCCL kernel then waits whole
-    slices for its peer."""
-    base = f"/sys/class/kfd/kfd/proc/{os.getpid()}/queues"
-    try:
-        out = {"total": 0}
-        for q in os.listdir(base):
-            try:
-                t = open(os.path.join(base, q, "type")).read().strip()
-            except OSError:
-                t = "?"
-            out["total"] += 1
-            out["type_" + t] = out.get("type_" + t, 0) + 1
-        return out
-    except OSError as e:
-        return {"error": type(e).__name__}
-
-
 FLOP_PER_PAIR = 20.0             # SURVEY.md 8(a) a2 / 8(d): the agreed algorithmic count
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
 FP64_VECTOR_PEAK_TFLOPS = 78.6
@@ -276,10 +257,11 @@ def main():
     ap.add_argument("--comm", default="torch", choices=["torch", "native"], help="who runs the step's two collectives: torch = "
                     "torch.distributed on the --backend group; native = the library's own RCCL communicator (nbody_comm_rccl_*), "
                     "its unique id broadcast through the --backend group, which then only carries barriers and reductions")
-    ap.add_argument("--comm-priority", default="auto", choices=["auto", "high", "normal"], help="priority of the communication stream(s): high = "
-                    "the device's greatest (RCCL's few workgroups are placed as soon as a slot frees, not behind the queued force workgroups), "
-                    "normal; auto = high when every rank has a GPU of its own, normal when ranks share one (--fake-hosts / gloo rehearsals: every "
-                    "priority level is one more hardware queue per process)")
+    ap.add_argument("--comm-priority", default="auto", choices=["auto", "high", "normal"], help="priority of the stream RCCL's kernels run on: normal "
+                    "(the library's default), high = the device's greatest (RCCL's few workgroups are placed ahead of the queued force workgroups; "
+                    "MEASURED PATHOLOGICAL when three or more processes share one GPU: profiles/r04a_rehearsal_priority_probe.txt), auto = normal, "
+                    "except with --comm native on a GPU per rank, where a few untimed steps are run both ways before the timed repeats and the faster "
+                    "setting is kept (both timings reported as config.rccl.comm_priority_ab)")
     ap.add_argument("--no-single-gpu-point", action="store_true", help="multi-GPU runs: skip rank 0's same-N single-GPU timing before the sharded phase")
     ap.add_argument("--fake-hosts", action="store_true", help="rehearsal only: give every rank its own NCCL_HOSTID so that RCCL "
                     "accepts several ranks on ONE GPU (it then talks over its socket transport on the loopback interface)")
@@ -312,8 +294,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     ndev = torch.cuda.device_count()
     shared_gpu = args.fake_hosts or (args.backend != "nccl" and args.comm != "native")
-    comm_priority = args.comm_priority if args.comm_priority != "auto" else ("normal" if shared_gpu and world > 1 else "high")
-    os.environ["NBODY_COMM_STREAM_PRIORITY"] = comm_priority      # read by nbody_shard_create
+    comm_priority = args.comm_priority if args.comm_priority != "auto" else "normal"
+    priority_ab = None
     if world > ndev and not shared_gpu:
         raise SystemExit(f"{world} ranks but {ndev} GPU(s): RCCL needs one GPU per rank (use --backend gloo, or --fake-hosts, to rehearse)")
     dev = torch.device("cuda", local_rank % ndev)
@@ -529,6 +511,24 @@ def main():
     run(steps_before_timing)
     barrier()
 
+    # ---- --comm-priority auto, library communicator, one GPU per rank: measure both settings on this machine, keep the faster ----
+    if multi and world > 1 and args.comm_priority == "auto" and args.comm == "native" and not shared_gpu:
+        phase("comm priority A/B")
+        k_ab = max(2, min(args.steps, 5))
+        ab = {}
+        for setting in ("normal", "high"):
+            sim.set_comm_priority(setting)
+            run(1)
+            barrier()
+            t0 = time.perf_counter()
+            run(k_ab)
+            barrier()
+            ab[setting] = max_over_ranks(time.perf_counter() - t0) / k_ab * 1e3
+        comm_priority = "high" if ab["high"] < 0.98 * ab["normal"] else "normal"      # the same on every rank: from reduced times
+        sim.set_comm_priority(comm_priority)
+        priority_ab = {"ms_per_step": ab, "steps_each": k_ab, "kept": comm_priority, "rule": "high only if more than 2 % faster"}
+        barrier()
+
     # ---- part 2: after the warm-up steps every rank's copy of every block must be bit-identical ----------------------------
     if check is not None:
         sim.refresh_positions()
@@ -579,11 +579,10 @@ def main():
             kernel_launches += launches
     ctx.timing(False)
     comm = sim.comm_report() if multi else None
-    if multi:   # hardware queues every rank holds on its GPU by now (ranks that share one GPU compete for its queue slots)
-        qs = [None] * world
-        dist.all_gather_object(qs, {"rank": rank, "pid": os.getpid(), **kfd_queue_census()})
-        rccl["kfd_queues"] = sorted(qs, key=lambda r: r["rank"])
+    if multi:
         rccl["comm_priority"] = comm_priority
+        if priority_ab:
+            rccl["comm_priority_ab"] = priority_ab
 
     # Equal masses (a Plummer sphere: every body 1/N) let the symmetric kernels factor the common mass out of the pair sums; the
     # decision is taken on the device per launch. Say whether the timed steps took that path, and time the GENERAL path (what a

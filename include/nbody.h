@@ -156,7 +156,7 @@ int nbody_ctx_set_fused(nbody_ctx* ctx, int mode);
  * The decision is made ON THE DEVICE, per launch, in stream order: a small scan kernel compares every body of the launch's ranges
  * with the first one (and checks that all coordinates are finite and within 1e15 of the origin: padding lanes sit at 1e18, where
  * their term underflows to exactly 0) and the force kernel reads its verdict — no host round trip, nothing to declare. Bodies
- * that are not uniform (the reference's own initial conditions: masses random in [1e8, 1e9]) take the general path, bit for bit
+ * that are not uniform (the reference's own initial conditions: masses uniform in [MIN_W, MAX_W] = [1e5, 1e9], constants.h:18-19) take the general path, bit for bit
  * as before. Same tolerances on either path; the two differ by rounding (m0 * sum(w r) against sum((m0 w) r)), each is bitwise
  * reproducible run to run. The scan is a dependent launch of its own, about 3 us per nbody_step call (once per call: the integrate
  * carries the masses through unchanged) or accel launch; never under graph replay. mode -1 (default): launches of 32768 bodies or
@@ -357,10 +357,11 @@ int nbody_shard_sync(nbody_shard* shard);
  * behind the first half of the own-block pass; mean exchange time and the part of it not hidden behind the second
  * half. Any out pointer may be NULL. */
 int nbody_shard_comm_timing(nbody_shard* shard, int enable);
-/* Priority of the rank's communication stream: 1 = the greatest the device offers (the default: RCCL's few channel
- * workgroups are placed as soon as a slot frees, not behind thousands of queued force workgroups), 0 = normal. Every
- * priority level in use is one more hardware queue of the process, so ranks that SHARE one GPU (rehearsals) may want 0.
- * Synchronises both streams and replaces the stream; call it between steps. */
+/* Priority of the rank's communication stream: 0 = normal (the default), 1 = the greatest the device offers (RCCL's few
+ * channel workgroups are then placed ahead of the queued force workgroups). Measured: with three or more processes
+ * sharing ONE GPU, 1 is pathological (hundreds of ms per step: spinning high-priority RCCL kernels of different
+ * processes); with a GPU per rank it is a knob to try (bench.py --comm native --comm-priority auto measures both).
+ * The stream is made on first use; a later call synchronises both streams and replaces it. Call between steps. */
 int nbody_shard_set_comm_priority(nbody_shard* shard, int high);
 int nbody_shard_comm_report(nbody_shard* shard, int* steps, double* gather_ms, double* gather_exposed_ms, double* exchange_ms,
                             double* exchange_exposed_ms);

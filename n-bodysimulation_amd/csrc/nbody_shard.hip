@@ -63,7 +63,7 @@ struct nbody_shard {
     int device = 0;
     hipStream_t compute = nullptr;  // the context's launch stream
     hipStream_t comm = nullptr;     // own
-    bool comm_high = true;
+    bool comm_high = false;         // measured default: normal priority
     nbody_comm cb{};
     bool have_comm = false;
     nbody_shard_plan_t plan{};
@@ -96,8 +96,11 @@ int check_shard(const nbody_shard* s)
 
 nbody_float4* nb(float4* p) { return reinterpret_cast<nbody_float4*>(p); }
 
-// The communication stream gets the highest priority the device offers unless asked otherwise: its few workgroups (RCCL's
-// channels) must be placed as soon as a slot frees up, not behind the thousands of queued force workgroups they run beside.
+// The communication stream. Normal priority by default. nbody_shard_set_comm_priority(.., 1) asks for the greatest priority the
+// device offers, so that RCCL's few channel workgroups are placed ahead of the thousands of queued force workgroups they run
+// beside — an option, not the default: with three or more processes on ONE GPU it was measured pathological (spinning
+// high-priority RCCL kernels of different processes: 622 ms per step against 1.26, profiles/r04a_rehearsal_priority_probe.txt),
+// and on a GPU per rank it has never been measured at all.
 int make_comm_stream(nbody_shard* s, bool high)
 {
     hipStream_t st = nullptr;

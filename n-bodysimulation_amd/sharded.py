@@ -151,8 +151,8 @@ class ShardedSimulation:
                  comm=None, comm_priority: Optional[str] = None, **kernel_opts):
         """comm: None or "torch" = the two collectives over torch.distributed (TorchComm; RCCL when the group's backend
         is nccl); "native" = the library's own RCCL communicator (NativeComm); or a ready TorchComm / NativeComm.
-        comm_priority: "high" (the library's default) or "normal" — the priority of the rank's communication stream
-        (nbody_shard_set_comm_priority; "normal" suits ranks that share one GPU)."""
+        comm_priority: "normal" (the library's default) or "high" — the priority of the rank's communication stream
+        (nbody_shard_set_comm_priority; only the library's own communicator launches RCCL's kernels on that stream)."""
         from .engine import Context
         bodies = np.ascontiguousarray(bodies, np.float32)
         if bodies.ndim != 2 or bodies.shape[1] != 4:
@@ -203,6 +203,12 @@ class ShardedSimulation:
                 raise ValueError("comm_priority must be 'high' or 'normal'")
             check(self._lib.nbody_shard_set_comm_priority(self._h, 1 if comm_priority == "high" else 0))
         check(self._lib.nbody_shard_upload(self._h, C.c_void_p(bodies.ctypes.data)))
+
+    def set_comm_priority(self, priority: str) -> None:
+        """nbody_shard_set_comm_priority between steps: "normal" or "high" (synchronises both streams)."""
+        if priority not in ("high", "normal"):
+            raise ValueError("comm_priority must be 'high' or 'normal'")
+        self._check(self._lib.nbody_shard_set_comm_priority(self._h, 1 if priority == "high" else 0))
 
     def reset(self, bodies: np.ndarray) -> None:
         """New bodies (same count) for every rank, at rest: nbody_shard_upload again (synchronous; every rank calls it

@@ -175,7 +175,7 @@ def check_multi_gpu_line(line, world, n, comm, distinct):
     assert c["sampled_bodies_per_rank"] >= 1024 and c["steps_checked"] >= 1
     rm = c["random_masses"]            # the same step on bodies of UNEQUAL masses: mass-weighted J-side sums through the exchange
     assert rm["finite"] and 0 <= rm["max_rel_da"] <= 5e-5
-    assert len(r["kfd_queues"]) == world and r["comm_priority"] in ("high", "normal")
+    assert r["comm_priority"] in ("high", "normal")
     if world > 1:                      # the same-N single-GPU point of the scaling series comes from THIS run, never from a file
         s1 = line["single_gpu_same_n"]
         assert s1["measured_in_this_run"] is True and s1["n_bodies"] == n and s1["value"] > 0 and s1["ms_per_step"] > 0

@@ -115,3 +115,17 @@ def test_fused_step_kernels_fit_one_workgroup_per_cu(kernels):
         t, wv, tile = (int(v) for v in name[len("nbk::step_fused<"):-1].split(",")[:3])     # <targets per wave, waves, tile, unroll>
         assert r["LDS Size"] == 2 * tile * 16 and r["LDS Size"] <= 160 * 1024, (name, r)
         assert r["Occupancy"] * 4 >= wv, (name, r)            # all waves of the workgroup resident on the CU's four SIMDs
+
+
+def test_every_global_kernel_of_the_product_header_is_instantiated_by_the_library(kernels):
+    """No orphans: every `__global__` template of the product's device header (csrc/nbody_kernels.hip.h) is instantiated by
+    libnbody_hip.so's sources (it shows up in the compiler's resource report of nbody_api.hip / nbody_shard.hip). Measured
+    alternatives that nothing ships live in tools/nbody_experiments.hip.h, not in the product header."""
+    hdr = open(os.path.join(ROOT, "n-bodysimulation_amd", "csrc", "nbody_kernels.hip.h")).read()
+    declared = set(re.findall(r"__global__\s+void[^;{]*?\b([a-z_0-9]+)\s*\(const", hdr))
+    assert len(declared) >= 15, declared
+    compiled = {re.sub(r"<.*$", "", k).replace("nbk::", "") for k in kernels}
+    assert declared <= compiled, f"kernels of the product header that the library never instantiates: {sorted(declared - compiled)}"
+    exp = open(os.path.join(ROOT, "tools", "nbody_experiments.hip.h")).read()
+    probes = set(re.findall(r"__global__\s+void[^;{]*?\b([a-z_0-9]+)\s*\(const", exp))
+    assert probes and not (probes & compiled), f"tools-only kernels found in the library: {sorted(probes & compiled)}"

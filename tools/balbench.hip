@@ -15,7 +15,7 @@
 #include <string>
 #include <vector>
 
-#include "nbody_kernels.hip.h"
+#include "nbody_experiments.hip.h"   // the product header + the measured alternatives
 
 #define CK(x)                                                                                     \
     do {                                                                                          \
