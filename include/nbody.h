@@ -148,6 +148,17 @@ int nbody_ctx_set_symmetric_runs(nbody_ctx* ctx, int mode);
  * integrate, as nbody_accel_range + nbody_integrate_range compute it: bit-identical to that pair); mode 1: whenever the kernel is FAST,
  * at any size. N = 8192, the reference's N_BODIES: 20.5 us per step against 25.7; N = 2048: 4.2 against 11.4. */
 int nbody_ctx_set_fused(nbody_ctx* ctx, int mode);
+/* The fused step IN PLACE: one launch reads and writes the caller's position array (a non-blocking protocol between the launch's
+ * workgroups decides per wave whether everything has been read; waves that cannot know write to the context's spare array and the
+ * last workgroup moves their positions home — same bits either way). mode -1 (default): nbody_simulate() — one synchronous step
+ * per call, the reference's loop (main.cpp:146-156) — runs its step in place and waits on a host-mapped word the launch writes
+ * when all its results are in memory, instead of a copy-back launch and a stream synchronisation (N = 8192: 30 us per call
+ * against 33.5); queued steps keep the two-array kernel, which is faster when nobody waits (20.3 against 23.6 us per step).
+ * 0: never (two arrays + copy-back, the round-3 behaviour); 1: every fused step; 2: as 1 with every wave forced down the
+ * fall-back path (tests). */
+int nbody_ctx_set_fused_inplace(nbody_ctx* ctx, int mode);
+/* Waves that took the fall-back path of the in-place step since the context was created (synchronises the stream). */
+int nbody_ctx_fused_inplace_stats(nbody_ctx* ctx, unsigned long long* out_fallback_waves);
 
 /* EQUAL-MASS systems (a Plummer model, most cluster and cosmological initial conditions: m_i = M / N). When every body a launch
  * touches has bit for bit the same mass m0, a_i = m0 * sum_j w_ij r_ij: the symmetric kernels then accumulate sum w r on both

@@ -81,6 +81,8 @@ _SIGNATURES = {
     "nbody_ctx_set_symmetric_runs": (C.c_int, [_p, C.c_int]),
     "nbody_ctx_autotune": (C.c_int, [_p, _p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "nbody_ctx_set_fused": (C.c_int, [_p, C.c_int]),
+    "nbody_ctx_set_fused_inplace": (C.c_int, [_p, C.c_int]),
+    "nbody_ctx_fused_inplace_stats": (C.c_int, [_p, C.POINTER(C.c_ulonglong)]),
     "nbody_ctx_set_equal_mass": (C.c_int, [_p, C.c_int]),
     "nbody_ctx_equal_mass_verdict": (C.c_int, [_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "nbody_ctx_set_workspace_limit": (C.c_int, [_p, C.c_size_t, C.c_int]),

@@ -7,6 +7,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <chrono>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -102,6 +105,17 @@ struct nbody_ctx {
     void* xalt = nullptr;      // the fused small-N step's second position array (positions alternate between it and the caller's)
     size_t xalt_bytes = 0;
     int fused = -1;            // fused small-N step: -1 where measurements prefer it (FAST, n <= kFusedMaxAuto), 0 never, 1 whenever FAST
+    // the fused step IN PLACE (nbk::step_fused<.., INPLACE>): counters + per-wave marks in device memory, a host-mapped word the
+    // launch writes when everything is visible (nbody_simulate spins on it instead of paying a stream synchronisation)
+    int fused_inplace = -1;    // -1 auto: the single step of nbody_simulate (no copy-back launch, host-mapped completion word); 0 never (two arrays + copy-back);
+                               //  1 every fused step; 2 every fused step AND every wave forced down the fall-back path (test hook)
+    unsigned* fsync = nullptr;         // nbk::kFusedSyncWords counters, then one byte per wave
+    size_t fsync_waves = 0;
+    unsigned* fhost = nullptr;         // host-mapped: [0] done value, [1] fall-backs so far
+    unsigned* fhost_dev = nullptr;     // its device address
+    unsigned fdone_seq = 0;            // value the last armed launch writes
+    bool fdone_armed = false;          // the last fused launch writes fhost[0] = fdone_seq at its end
+    bool want_host_done = false;       // nbody_simulate: arm the next in-place launch
     unsigned long long ws_tag = 0;     // which balanced-run layout the `slabs` workspace is cleared for (0 = none: any other user of it)
     bool ws_fail_above_limit = false;  // test hook: allocations above ws_limit are attempted and FAIL (out of memory) instead of
                                // being avoided by the shape choice
@@ -467,20 +481,56 @@ int ensure_xalt(nbody_ctx* c, int n)
     return NBODY_OK;
 }
 
-template <int T>
+// the in-place fused step's counters and per-wave marks (zeroed once: every launch leaves them zero), and its host-mapped word
+int ensure_fsync(nbody_ctx* c, size_t nwaves)
+{
+    if (!c->fhost) {
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&c->fhost), 64, hipHostMallocMapped | hipHostMallocCoherent);
+        if (e == hipSuccess) {
+            c->fhost[0] = c->fhost[1] = 0;
+            e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->fhost_dev), c->fhost, 0);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            if (c->fhost) (void)hipHostFree(c->fhost);
+            c->fhost = c->fhost_dev = nullptr;
+            return fail(NBODY_ERR_NOMEM, "cannot allocate the fused step's host-mapped word: %s", hipGetErrorString(e));
+        }
+    }
+    if (c->fsync && nwaves <= c->fsync_waves) return NBODY_OK;
+    if (c->fsync) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipFree(c->fsync));
+        c->fsync = nullptr;
+        c->fsync_waves = 0;
+    }
+    const size_t waves = nwaves < 4096 ? 4096 : nwaves;
+    const size_t bytes = nbk::kFusedSyncWords * sizeof(unsigned) + waves;
+    const hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->fsync), bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        c->fsync = nullptr;
+        return fail(NBODY_ERR_NOMEM, "cannot allocate the fused step's counters (%zu bytes): %s", bytes, hipGetErrorString(e));
+    }
+    HIP_TRY(hipMemsetAsync(c->fsync, 0, bytes, c->stream));
+    c->fsync_waves = waves;
+    return NBODY_OK;
+}
+
+template <int T, bool INPLACE>
 int launch_fused_t(const FusedShape& f, const nbk::FusedParams& p, hipStream_t st)
 {
     // <targets per wave, waves per workgroup, tile, unroll of the per-lane source loop>: the unroll measured better per shape
     // (profiles/r03_smalln_probe.jsonl; N = 8192: 21.07 us at 4, 20.36 at 8; N = 4096: 7.99 at 4, 8.72 at 8)
     switch (f.wv) {
-        case 2: nbk::step_fused<T, 2, 2048, 8><<<f.grid, 128, 0, st>>>(p); break;
-        case 4: nbk::step_fused<T, 4, 2048, 8><<<f.grid, 256, 0, st>>>(p); break;
-        case 6: nbk::step_fused<T, 6, 2304, 4><<<f.grid, 384, 0, st>>>(p); break;
-        case 8: nbk::step_fused<T, 8, 2048, 4><<<f.grid, 512, 0, st>>>(p); break;
-        case 10: nbk::step_fused<T, 10, 2560, 8><<<f.grid, 640, 0, st>>>(p); break;
-        case 12: nbk::step_fused<T, 12, 2304, 4><<<f.grid, 768, 0, st>>>(p); break;
-        case 14: nbk::step_fused<T, 14, 2688, 8><<<f.grid, 896, 0, st>>>(p); break;
-        case 16: nbk::step_fused<T, 16, 2048, 8><<<f.grid, 1024, 0, st>>>(p); break;
+        case 2: nbk::step_fused<T, 2, 2048, 8, 1, INPLACE><<<f.grid, 128, 0, st>>>(p); break;
+        case 4: nbk::step_fused<T, 4, 2048, 8, 1, INPLACE><<<f.grid, 256, 0, st>>>(p); break;
+        case 6: nbk::step_fused<T, 6, 2304, 4, 1, INPLACE><<<f.grid, 384, 0, st>>>(p); break;
+        case 8: nbk::step_fused<T, 8, 2048, 4, 1, INPLACE><<<f.grid, 512, 0, st>>>(p); break;
+        case 10: nbk::step_fused<T, 10, 2560, 8, 1, INPLACE><<<f.grid, 640, 0, st>>>(p); break;
+        case 12: nbk::step_fused<T, 12, 2304, 4, 1, INPLACE><<<f.grid, 768, 0, st>>>(p); break;
+        case 14: nbk::step_fused<T, 14, 2688, 8, 1, INPLACE><<<f.grid, 896, 0, st>>>(p); break;
+        case 16: nbk::step_fused<T, 16, 2048, 8, 1, INPLACE><<<f.grid, 1024, 0, st>>>(p); break;
         default: return 1;
     }
     return 0;
@@ -800,7 +850,8 @@ int launch_bal_reduce(nbody_ctx* c, const nbk::BalReduceParams& r)
 int launch_fused(nbody_ctx* c, const FusedShape& f, const nbk::FusedParams& p, bool timed)
 {
     if (timed) if (int rc = time_mark(c)) return rc;
-    const int bad = f.T == 2 ? launch_fused_t<2>(f, p, c->stream) : launch_fused_t<4>(f, p, c->stream);
+    const int bad = p.sync ? (f.T == 2 ? launch_fused_t<2, true>(f, p, c->stream) : launch_fused_t<4, true>(f, p, c->stream))
+                           : (f.T == 2 ? launch_fused_t<2, false>(f, p, c->stream) : launch_fused_t<4, false>(f, p, c->stream));
     if (bad) return fail(NBODY_ERR_CONFIG, "no fused step kernel for T=%d waves=%d", f.T, f.wv);
     HIP_TRY(hipGetLastError());
     if (timed) return time_mark(c);
@@ -909,6 +960,8 @@ int nbody_ctx_destroy(nbody_ctx* c)
     if (c->slabs) (void)hipFree(c->slabs);
     if (c->xslabs) (void)hipFree(c->xslabs);
     if (c->xalt) (void)hipFree(c->xalt);
+    if (c->fsync) (void)hipFree(c->fsync);
+    if (c->fhost) (void)hipHostFree(c->fhost);
     if (c->eqm) (void)hipFree(c->eqm);
     if (c->legacy_buf) (void)hipFree(c->legacy_buf);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
@@ -997,6 +1050,29 @@ int nbody_ctx_set_fused(nbody_ctx* c, int mode)
     return NBODY_OK;
 }
 
+int nbody_ctx_set_fused_inplace(nbody_ctx* c, int mode)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (mode < -1 || mode > 2)
+        return fail(NBODY_ERR_CONFIG, "fused in-place mode must be -1 (auto), 0 (never), 1 (every fused step) or 2 (every step, fall-back path forced)");
+    c->fused_inplace = mode;
+    return NBODY_OK;
+}
+
+int nbody_ctx_fused_inplace_stats(nbody_ctx* c, unsigned long long* out_fallback_waves)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (!out_fallback_waves) return fail(NBODY_ERR_INVALID, "null out");
+    *out_fallback_waves = 0;
+    if (!c->fsync) return NBODY_OK;
+    ON_DEVICE(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    unsigned total = 0;
+    HIP_TRY(hipMemcpy(&total, c->fsync + nbk::kFusedFallbacksTotal, sizeof total, hipMemcpyDeviceToHost));
+    *out_fallback_waves = total;
+    return NBODY_OK;
+}
+
 int nbody_ctx_set_equal_mass(nbody_ctx* c, int mode)
 {
     if (int rc = check_ctx(c)) return rc;
@@ -1056,8 +1132,14 @@ int nbody_ctx_reserve(nbody_ctx* c, int n_targets)
     }
     {
         FusedShape fs{};
-        if (fused_wanted(c, n_targets, &fs)) (void)ensure_xalt(c, n_targets);   // whole steps of this size run the fused kernel; the workspace below
-    }                                                                           // still serves nbody_accel_range on such a block
+        if (fused_wanted(c, n_targets, &fs)) {   // whole steps of this size run the fused kernel; the workspace below
+            (void)ensure_xalt(c, n_targets);     // still serves nbody_accel_range on such a block
+            if (c->fused_inplace != 0) (void)ensure_fsync(c, (size_t)fs.grid * fs.wv);
+        }
+        // the device code of this library is loaded by the runtime on first use (milliseconds): now, not inside the first timed step
+        hipFuncAttributes attr;
+        if (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&nbk::copy_bodies)) != hipSuccess) (void)hipGetLastError();
+    }
     for (int attempt = 0;; ++attempt) {
         BalShape by{};
         if (bal_wanted(c, n_targets, &by)) {
@@ -1559,21 +1641,51 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
     ON_DEVICE(c);
     FusedShape fs{};
     if (fused_wanted(c, n, &fs) && ensure_xalt(c, n) == NBODY_OK) {   // (no spare array to be had: the two-kernel paths below)
-        // small systems: one launch per step (force + integrate), positions alternating between the caller's array and a spare one
+        // small systems: one launch per step (force + integrate). Two-array kernel: positions alternate between the caller's array
+        // and a spare one, and an odd number of steps ends with a copy-back launch. In-place kernel (nbk::step_fused<.., INPLACE>): the
+        // caller's array is read and written by the same launch. Default: two-array launches in pairs, the odd last step in place.
         float4* const xa = reinterpret_cast<float4*>(d_bodies);
         float4* const xb = static_cast<float4*>(c->xalt);
+        const int mode = c->timing ? 0 : c->fused_inplace;     // (instrumented runs keep the plain kernel: one event pair per launch)
+        // default (-1): in place only where it pays — the odd last step of a call whose caller will wait on the launch's host-mapped
+        // word (nbody_simulate). Queued, the two-array kernel is 3.4 us per step faster (the in-place launch ends with a chain of
+        // round trips: look at the counter, stores through the L2, count out), and a copy-back launch costs 2.1 (profiles/r04_sync_probe_*.txt).
+        const bool auto_inplace = mode < 0 && c->want_host_done && (steps & 1);
+        const bool any_inplace = mode >= 1 || auto_inplace;
+        if (any_inplace) if (int rc = ensure_fsync(c, (size_t)fs.grid * fs.wv)) return rc;
         nbk::FusedParams fp{};
         fp.v = reinterpret_cast<float4*>(d_velocity);
         fp.a = reinterpret_cast<float4*>(d_accelerations);
         fp.n = n;
         fp.dt = c->dt;
         fp.eps2 = c->eps2;
+        c->fdone_armed = false;
+        int parity = 0;   // 0: the current positions are in the caller's array
         for (int k = 0; k < steps; ++k) {
-            fp.xin = (k & 1) ? xb : xa;
-            fp.xout = (k & 1) ? xa : xb;
+            const bool inplace = mode >= 1 || (auto_inplace && k == steps - 1 && parity == 0);
+            if (inplace && parity == 0) {
+                fp.xin = xa;
+                fp.xout = xb;
+                fp.sync = c->fsync;
+                fp.fb = reinterpret_cast<unsigned char*>(c->fsync + nbk::kFusedSyncWords);
+                fp.force_fallback = mode == 2;
+                fp.host_word = nullptr;
+                if (k == steps - 1 && c->want_host_done) {   // the caller (nbody_simulate) will spin on the host-mapped word
+                    fp.host_word = c->fhost_dev;
+                    fp.done_value = ++c->fdone_seq;
+                    c->fdone_armed = true;
+                }
+            } else {
+                fp.xin = parity ? xb : xa;
+                fp.xout = parity ? xa : xb;
+                fp.sync = nullptr;
+                fp.fb = nullptr;
+                fp.host_word = nullptr;
+                parity ^= 1;
+            }
             if (int rc = launch_fused(c, fs, fp, c->timing)) return rc;
         }
-        if (steps & 1) {   // the result belongs in the caller's array
+        if (parity) {   // the result belongs in the caller's array
             nbk::copy_bodies<<<(n + 255) / 256, 256, 0, c->stream>>>(xa, xb, n);
             HIP_TRY(hipGetLastError());
         }
@@ -1850,8 +1962,27 @@ int nbody_simulate(nbody_float4* d_bodies, nbody_float4* d_accelerations, nbody_
     std::lock_guard<std::recursive_mutex> lk(g_default_mu);
     nbody_ctx* c = nullptr;
     if (int rc = nbody_default_ctx(&c)) return rc;
-    if (int rc = nbody_step(c, d_bodies, d_accelerations, d_velocity, n, 1)) return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));  // simulate() is synchronous: kernel.cu:644
+    c->want_host_done = true;    // a fused in-place step ends by writing a host-mapped word once all its results are visible
+    const int rc = nbody_step(c, d_bodies, d_accelerations, d_velocity, n, 1);
+    c->want_host_done = false;
+    if (rc) return rc;
+    // simulate() is synchronous (kernel.cu:644). Waiting for the launch's own word costs about 4 us less per call than
+    // hipStreamSynchronize (profiles/r04_sync_probe_*.txt); the stream synchronisation stays as the backstop (and reports errors).
+    if (c->fdone_armed) {
+        c->fdone_armed = false;
+        volatile unsigned* const w = c->fhost;
+        const unsigned want = c->fdone_seq;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; ++spins) {
+            if (*w == want) {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                return NBODY_OK;
+            }
+            if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(2000)) break;
+        }
+    }
+    ON_DEVICE(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return NBODY_OK;
 }
 

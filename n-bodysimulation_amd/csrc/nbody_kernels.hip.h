@@ -1419,6 +1419,25 @@ __global__ void __launch_bounds__(64 * P) bal_reduce(const BalReduceParams p)
 // spare one and copies back after an odd number of steps). 12 packed ops + 2 v_rsq_f32 per two pairs, the one-sided count (35
 // cycles per 64 pairs with the LDS reads): 16 us of VALU work at N = 8192 in a 20.5 us step, against 25.7 us for force + partial
 // sums + reduce in two launches.
+// A float4 stored / loaded at SYSTEM scope (two 64-bit relaxed atomics: global_store_dwordx2 sc0 sc1 — through the L2 to memory)
+__device__ __forceinline__ void store_f4_system(float4* dst, const float4 v)
+{
+    unsigned long long* const q = reinterpret_cast<unsigned long long*>(dst);
+    const unsigned long long lo = (unsigned long long)__builtin_bit_cast(unsigned, v.x) | ((unsigned long long)__builtin_bit_cast(unsigned, v.y) << 32);
+    const unsigned long long hi = (unsigned long long)__builtin_bit_cast(unsigned, v.z) | ((unsigned long long)__builtin_bit_cast(unsigned, v.w) << 32);
+    __hip_atomic_store(q, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(q + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__device__ __forceinline__ float4 load_f4_system(const float4* src)
+{
+    unsigned long long* const q = reinterpret_cast<unsigned long long*>(const_cast<float4*>(src));
+    const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return make_float4(__builtin_bit_cast(float, (unsigned)lo), __builtin_bit_cast(float, (unsigned)(lo >> 32)),
+                       __builtin_bit_cast(float, (unsigned)hi), __builtin_bit_cast(float, (unsigned)(hi >> 32)));
+}
+
 struct FusedParams {
     const float4* xin;   // positions at the start of the step
     float4* xout;        // advanced positions (another array: every wave reads xin until the end of the launch)
@@ -1426,7 +1445,16 @@ struct FusedParams {
     float4* a;           // accelerations (output)
     int n;
     float dt, eps2;
+    // in-place variant only (step_fused<.., INPLACE = true>): xin == the caller's array, xout == the context's spare array
+    unsigned* sync;                 // FusedSync words (device memory, zero between launches)
+    unsigned char* fb;              // one byte per wave of the grid: 1 = this wave's advanced positions are in xout, not in place
+    volatile unsigned* host_word;   // host-mapped: [0] = done_value once everything (repair included) is visible system-wide, [1] = fall-backs so far
+    unsigned done_value;
+    int force_fallback;             // test hook: every wave takes the fall-back path
 };
+
+// Device words of the in-place protocol.
+enum FusedSync : int { kFusedReaders = 0, kFusedFinished = 1, kFusedFallbacks = 2, kFusedFallbacksTotal = 3, kFusedSyncWords = 4 };
 
 // dst[i] = src[i]: puts the positions of an odd step back into the caller's array (a launch on the same stream costs less than a
 // device-to-device hipMemcpyAsync of 128 KiB)
@@ -1436,7 +1464,21 @@ __global__ void __launch_bounds__(256) copy_bodies(float4* __restrict__ dst, con
     if (i < n) dst[i] = src[i];
 }
 
-template <int T, int WV, int TILE, int UNROLL = 8, int MINW = 1>
+// INPLACE = true: the same step with the advanced positions written back INTO the array they were read from — one launch, no spare
+// array to alternate with, no copy-back launch after an odd number of steps (what a caller who steps once per synchronous call, like
+// the reference's loop main.cpp:146-156, pays every call). In place is only safe once EVERY workgroup has read everything it will
+// ever read; the launch is one workgroup per CU, normally all resident at once, but nothing guarantees that (another process or
+// stream may hold CUs), so the protocol NEVER WAITS for a workgroup that has not started:
+//   * a workgroup counts itself in `readers` (release) once its last source tile has landed in LDS — a quarter of its run time before
+//     it ends;
+//   * at its end a wave looks at `readers` (acquire; a few polls at most, bounded): all workgroups counted -> its positions go in place;
+//     otherwise -> to the spare array, with a mark in `fb` (a workgroup that starts later still reads the OLD positions: correct);
+//   * every workgroup counts itself in `finished` (release) after its stores; the one that completes the count knows that all reads
+//     and all writes of the launch are done: it moves marked positions into place (rare), zeroes the counters for the next launch,
+//     and writes the host-mapped word — the caller may spin on that instead of paying a stream synchronisation.
+// Every path ends without waiting on another wave: no deadlock whatever shares the GPU. Same arithmetic and the same bits as the
+// two-array kernel (tests: test_fused_step_inplace_*).
+template <int T, int WV, int TILE, int UNROLL = 8, int MINW = 1, bool INPLACE = false>
 __global__ void __launch_bounds__(64 * WV, MINW) step_fused(const FusedParams p)
 {
     static_assert(T % 2 == 0 && TILE % (64 * WV) == 0, "packed targets, whole loads per thread");
@@ -1473,6 +1515,12 @@ __global__ void __launch_bounds__(64 * WV, MINW) step_fused(const FusedParams p)
         for (int l = 0; l < LPT; ++l) sh[buf][l * (64 * WV) + tid] = pre[l];
         __syncthreads();   // one barrier per tile: the other buffer is rewritten only after every wave has passed the next one
         if (jt + TILE < p.n) fetch(jt + TILE);
+        else if (INPLACE && tid == 0)
+            // The last tile is in LDS, x_own and the targets long since in registers: this workgroup has READ all it ever will. Every
+            // load of the workgroup has returned its data before the barrier above (the data went to LDS), so a relaxed atomic — agent
+            // scope: one counter for all eight XCDs — is ordered behind them by construction; a release here would add an L2
+            // write-back to the critical path for stores that do not exist yet.
+            __hip_atomic_fetch_add(p.sync + kFusedReaders, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int left = p.n - jt;
         if (left >= TILE) {
 #pragma unroll UNROLL
@@ -1496,27 +1544,89 @@ __global__ void __launch_bounds__(64 * WV, MINW) step_fused(const FusedParams p)
         const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
         return ((r0 + r1) + r2) + r3;
     };
+    // (in place: the look at `readers` is issued before the reduction, so its round trip to the L2 runs beside it)
+    unsigned seen = 0;
+    if (INPLACE && mine) seen = __hip_atomic_load(p.sync + kFusedReaders, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float4 tot[T];
 #pragma unroll
     for (int k = 0; k < T; ++k) {
         const float4 s = t.acc(k);
         tot[k] = make_float4(wave_sum(s.x), wave_sum(s.y), wave_sum(s.z), 0.0f);
     }
-    if (!mine) return;
-    float4 acc = tot[0];
+    if (!INPLACE && !mine) return;
+    if (mine) {
+        float4 acc = tot[0];
 #pragma unroll
-    for (int k = 1; k < T; ++k) if (lane == k) acc = tot[k];
-    {
-#pragma clang fp contract(off)
+        for (int k = 1; k < T; ++k) if (lane == k) acc = tot[k];
+        bool in_place = false;
+        if (INPLACE) {   // have all workgroups of the launch read everything? (a few polls, then the fall-back: never an unbounded wait)
+            // (relaxed: nothing is READ on the strength of this value — the store below is issued only after the load has returned)
+            for (int poll = 0; poll < 16 && seen != gridDim.x; ++poll) {
+                __builtin_amdgcn_s_sleep(8);
+                seen = __hip_atomic_load(p.sync + kFusedReaders, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            in_place = seen == gridDim.x && !p.force_fallback;
+        }
         acc.w = 0.0f;
         float4 x = x_own;
         float4 v = v_own;
-        const float hdt = 0.5f * p.dt;
-        v.x += hdt * acc.x; v.y += hdt * acc.y; v.z += hdt * acc.z;
-        x.x += p.dt * v.x; x.y += p.dt * v.y; x.z += p.dt * v.z;
-        p.a[i] = acc;
-        p.v[i] = v;
-        p.xout[i] = x;   // .w (mass) carried through
+        {
+#pragma clang fp contract(off)
+            const float hdt = 0.5f * p.dt;
+            v.x += hdt * acc.x; v.y += hdt * acc.y; v.z += hdt * acc.z;
+            x.x += p.dt * v.x; x.y += p.dt * v.y; x.z += p.dt * v.z;
+        }
+        if (!INPLACE) {
+            p.a[i] = acc;
+            p.v[i] = v;
+            p.xout[i] = x;   // .w (mass) carried through
+        } else {
+            // In place, results are stored THROUGH the L2 (system scope): the workgroup that ends the launch tells the host so while the
+            // kernel is still winding down, and eight XCDs' L2s are not coherent for ordinary stores; a write-back fence per workgroup
+            // instead (buffer_wbl2) cost 8 us per step (profiles/r04_fused_inplace_wbl2.txt).
+            store_f4_system(p.a + i, acc);
+            store_f4_system(p.v + i, v);
+            store_f4_system((in_place ? const_cast<float4*>(p.xin) : p.xout) + i, x);
+            if (!in_place && lane == 0) {
+                __hip_atomic_store(p.fb + ((int)blockIdx.x * WV + w), (unsigned char)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_fetch_add(p.sync + kFusedFallbacks, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    if (!INPLACE) return;
+    // Every workgroup counts itself out once its stores are complete (the barrier waits for them: s_waitcnt vmcnt(0), and a
+    // system-scope store is complete when memory has it); the workgroup that completes the count ends the launch.
+    __syncthreads();
+    if (w != 0) return;   // the first wave alone ends the workgroup's part (and, if it is the last workgroup's, the launch)
+    unsigned before = 0;
+    if (lane == 0) before = __hip_atomic_fetch_add(p.sync + kFusedFinished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    before = (unsigned)__builtin_amdgcn_readfirstlane((int)before);
+    if (before + 1 != gridDim.x) return;
+    const unsigned nfb = __hip_atomic_load(p.sync + kFusedFallbacks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (nfb != 0) {   // rare: some waves could not write in place; all reads of the launch are over now, so their positions go home
+        const int nwaves = (int)gridDim.x * WV;
+        float4* const x = const_cast<float4*>(p.xin);
+        for (int wq = lane; wq < nwaves; wq += 64) {
+            if (!__hip_atomic_load(p.fb + wq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) continue;
+            __hip_atomic_store(p.fb + wq, (unsigned char)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            for (int k = 0; k < T; ++k) {
+                const int q = wq * T + k;
+                if (q < p.n) store_f4_system(x + q, load_f4_system(p.xout + q));
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);   // these stores complete before the host hears of the launch (one wave: no barrier needed)
+    }
+    if (lane == 0) {
+        const unsigned total = p.sync[kFusedFallbacksTotal] + nfb;
+        p.sync[kFusedFallbacksTotal] = total;
+        __hip_atomic_store(p.sync + kFusedReaders, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.sync + kFusedFinished, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.sync + kFusedFallbacks, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p.host_word) {   // every result of the launch is in memory by now (see above): tell the host
+            __hip_atomic_store(const_cast<unsigned*>(p.host_word) + 1, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __builtin_amdgcn_s_waitcnt(0);   // the count before the word the host waits for
+            __hip_atomic_store(const_cast<unsigned*>(p.host_word), p.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 

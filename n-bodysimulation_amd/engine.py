@@ -109,6 +109,17 @@ class Context:
         """The fused small-N step (force + integrate in one launch): -1 where measurements prefer it, 0 never, 1 always (FAST)."""
         check(self._lib.nbody_ctx_set_fused(self._h, mode))
 
+    def set_fused_inplace(self, mode: int) -> None:
+        """The fused step in place: -1 the odd last step of a call (default), 0 never (two arrays + copy-back), 1 every fused
+        step, 2 every step with the fall-back path forced (tests)."""
+        check(self._lib.nbody_ctx_set_fused_inplace(self._h, mode))
+
+    def fused_inplace_fallbacks(self) -> int:
+        """Waves that took the in-place step's fall-back path so far (synchronises)."""
+        out = C.c_ulonglong()
+        check(self._lib.nbody_ctx_fused_inplace_stats(self._h, C.byref(out)))
+        return out.value
+
     def set_equal_mass(self, mode: int) -> None:
         """Equal-mass path of the symmetric kernels (decided on the device, per launch, by a scan of the masses): -1 launches of
         32768 bodies or more, 1 launches of 4096 bodies or more, 0 never."""

@@ -109,10 +109,12 @@ def test_fused_step_kernels_fit_one_workgroup_per_cu(kernels):
     """The fused small-N step runs one workgroup of 2 ... 16 waves per CU: every instantiation must fit (VGPRs of 16 waves:
     at most 128 each; LDS: the double-buffered source tile), without scratch."""
     names = [k for k in kernels if k.startswith("nbk::step_fused<")]
-    assert len(names) == 16, names
+    assert len(names) == 32, names                           # 2 targets-per-wave x 8 workgroup sizes x {two arrays, in place}
     for name in names:
         r = kernels[name]
-        t, wv, tile = (int(v) for v in name[len("nbk::step_fused<"):-1].split(",")[:3])     # <targets per wave, waves, tile, unroll>
+        args = name[len("nbk::step_fused<"):-1].split(",")    # <targets per wave, waves, tile, unroll, min waves, in place>
+        t, wv, tile = (int(v) for v in args[:3])
+        assert args[5].strip() in ("true", "false")
         assert r["LDS Size"] == 2 * tile * 16 and r["LDS Size"] <= 160 * 1024, (name, r)
         assert r["Occupancy"] * 4 >= wv, (name, r)            # all waves of the workgroup resident on the CU's four SIMDs
 

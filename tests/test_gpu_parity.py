@@ -1247,6 +1247,62 @@ def test_fused_step_split_calls_and_the_simulate_boundary(nb, oracle):
     assert np.abs(big.state()[2][:512] - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 1e-5
 
 
+@pytest.mark.parametrize("n,init", [(1, 0), (2, 1), (63, 0), (129, 1), (1000, 0), (2048, 1), (3001, 0), (4096, 1), (6144, 0), (8000, 1), (8192, 0)])
+def test_fused_step_in_place_is_bit_identical_to_the_two_array_step(nb, n, init):
+    """nbk::step_fused<.., INPLACE>: the caller's position array read and written by ONE launch (a non-blocking protocol between the
+    workgroups decides per wave whether everybody has read; waves that cannot know write to the spare array and the last workgroup
+    moves their positions home). Same arithmetic, so the same BITS as the two-array kernel + copy-back — in every mode: the default
+    (the odd last step of a call in place), every step in place, and every wave forced down the fall-back path (mode 2: the repair
+    by the last workgroup carries the whole result); odd and even step counts, steps split over calls."""
+    x0 = nb.engine.seeded_bodies(n, init, 4242)
+    dt = 0.1 if init == 0 else 0.01
+    waves = (n + 1) // 2 if n <= 8192 else 0
+
+    def run(mode, calls):
+        sim = nb.engine.Simulation(x0, dt=dt, eps2=0.002)
+        assert sim.ctx.step_info(n)["fused"]
+        sim.ctx.set_fused_inplace(mode)
+        for k in calls:
+            sim.run(k)
+        return sim.state(), sim.ctx.fused_inplace_fallbacks()
+
+    want, fb0 = run(0, (5,))
+    assert fb0 == 0
+    for mode, calls in ((-1, (5,)), (-1, (1, 1, 3)), (-1, (2, 3)), (1, (5,)), (1, (1, 4)), (2, (5,)), (2, (3, 1, 1))):
+        got, fb = run(mode, calls)
+        for p, q in zip(want, got):
+            assert np.array_equal(p, q), (mode, calls)
+        if mode == 2:      # every wave of every in-place launch took the fall-back path and was repaired
+            assert fb == waves * 5, (fb, waves)
+    want4, _ = run(0, (4,))
+    for mode in (-1, 1, 2):
+        got, _ = run(mode, (4,))
+        for p, q in zip(want4, got):
+            assert np.array_equal(p, q), mode
+
+
+def test_simulate_takes_the_in_place_step_and_its_host_word(nb, oracle):
+    """simulate() — one synchronous step per call, the reference's loop (main.cpp:146-156) — runs the in-place fused step and
+    waits on the host-mapped word the launch writes. The device arrays must be complete when the call returns: they are read back
+    at once, by a plain copy, after every call, and compared bit for bit with the queued two-array run."""
+    dev = torch.device("cuda", 0)
+    for n in (8192, 3000, 100):
+        x0 = nb.engine.seeded_bodies(n, 0, 9)
+        ref = nb.engine.Simulation(x0)                                   # DT 0.1 / EPS2 0.002: the defaults simulate() runs with
+        ref.ctx.set_fused_inplace(0)
+        x = torch.from_numpy(x0).to(dev)
+        v, a = torch.zeros_like(x), torch.zeros_like(x)
+        for k in range(1, 8):
+            nb.engine.simulate(x, a, v)
+            got = (x.cpu().numpy(), v.cpu().numpy(), a.cpu().numpy())    # straight after the call returns
+            ref.run(1)
+            for p, q in zip(ref.state(), got):
+                assert np.array_equal(p, q), (n, k)
+    xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
+    oracle.step_jacobi(xo, ao, vo, dt=0.1, eps2=0.002, steps=7)
+    assert np.abs(got[0] - xo)[:, :3].max() / 1e5 <= 1e-6
+
+
 def test_autotune_measures_and_sets_the_knobs(nb, oracle):
     """nbody_ctx_autotune: times the decompositions that apply to whole steps of n bodies on the device at hand (scratch copies,
     dt = 0: the caller's array is only read) and leaves the context on the fastest. On MI355X that reproduces the built-in choice at
