@@ -111,8 +111,8 @@ struct nbody_ctx {
                                //  1 every fused step; 2 every fused step AND every wave forced down the fall-back path (test hook)
     unsigned* fsync = nullptr;         // nbk::kFusedSyncWords counters, then one byte per wave
     size_t fsync_waves = 0;
-    unsigned* fhost = nullptr;         // host-mapped: [0] done value, [1] fall-backs so far
-    unsigned* fhost_dev = nullptr;     // its device address
+    unsigned long long* fhost = nullptr;      // host-mapped 64-bit word: low half = done value, high half = fall-back waves of that launch
+    unsigned long long* fhost_dev = nullptr;  // its device address
     unsigned fdone_seq = 0;            // value the last armed launch writes
     bool fdone_armed = false;          // the last fused launch writes fhost[0] = fdone_seq at its end
     bool want_host_done = false;       // nbody_simulate: arm the next in-place launch
@@ -487,7 +487,7 @@ int ensure_fsync(nbody_ctx* c, size_t nwaves)
     if (!c->fhost) {
         hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&c->fhost), 64, hipHostMallocMapped | hipHostMallocCoherent);
         if (e == hipSuccess) {
-            c->fhost[0] = c->fhost[1] = 0;
+            c->fhost[0] = 0;
             e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->fhost_dev), c->fhost, 0);
         }
         if (e != hipSuccess) {
@@ -1970,11 +1970,11 @@ int nbody_simulate(nbody_float4* d_bodies, nbody_float4* d_accelerations, nbody_
     // hipStreamSynchronize (profiles/r04_sync_probe_*.txt); the stream synchronisation stays as the backstop (and reports errors).
     if (c->fdone_armed) {
         c->fdone_armed = false;
-        volatile unsigned* const w = c->fhost;
+        volatile unsigned long long* const w = c->fhost;
         const unsigned want = c->fdone_seq;
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned spins = 0;; ++spins) {
-            if (*w == want) {
+            if ((unsigned)*w == want) {
                 std::atomic_thread_fence(std::memory_order_acquire);
                 return NBODY_OK;
             }

@@ -1448,13 +1448,15 @@ struct FusedParams {
     // in-place variant only (step_fused<.., INPLACE = true>): xin == the caller's array, xout == the context's spare array
     unsigned* sync;                 // FusedSync words (device memory, zero between launches)
     unsigned char* fb;              // one byte per wave of the grid: 1 = this wave's advanced positions are in xout, not in place
-    volatile unsigned* host_word;   // host-mapped: [0] = done_value once everything (repair included) is visible system-wide, [1] = fall-backs so far
+    unsigned long long* host_word;  // host-mapped, ONE 64-bit store once everything (repair included) is in memory: low half = done_value, high half = fall-backs of this launch
     unsigned done_value;
     int force_fallback;             // test hook: every wave takes the fall-back path
 };
 
 // Device words of the in-place protocol.
-enum FusedSync : int { kFusedReaders = 0, kFusedFinished = 1, kFusedFallbacks = 2, kFusedFallbacksTotal = 3, kFusedSyncWords = 4 };
+// kFusedFinished counts workgroups in its low half and fall-back waves in its high half (a wave's mark precedes its workgroup's
+// count, so the workgroup that completes the count reads both in the one value its atomic returns: one round trip, not two).
+enum FusedSync : int { kFusedReaders = 0, kFusedFinished = 1, kFusedFallbacksTotal = 2, kFusedSyncWords = 4 };
 
 // dst[i] = src[i]: puts the positions of an odd step back into the caller's array (a launch on the same stream costs less than a
 // device-to-device hipMemcpyAsync of 128 KiB)
@@ -1589,7 +1591,7 @@ __global__ void __launch_bounds__(64 * WV, MINW) step_fused(const FusedParams p)
             store_f4_system((in_place ? const_cast<float4*>(p.xin) : p.xout) + i, x);
             if (!in_place && lane == 0) {
                 __hip_atomic_store(p.fb + ((int)blockIdx.x * WV + w), (unsigned char)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_fetch_add(p.sync + kFusedFallbacks, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(p.sync + kFusedFinished, 1u << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -1601,8 +1603,8 @@ __global__ void __launch_bounds__(64 * WV, MINW) step_fused(const FusedParams p)
     unsigned before = 0;
     if (lane == 0) before = __hip_atomic_fetch_add(p.sync + kFusedFinished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     before = (unsigned)__builtin_amdgcn_readfirstlane((int)before);
-    if (before + 1 != gridDim.x) return;
-    const unsigned nfb = __hip_atomic_load(p.sync + kFusedFallbacks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((before & 0xffffu) + 1 != gridDim.x) return;
+    const unsigned nfb = before >> 16;
     if (nfb != 0) {   // rare: some waves could not write in place; all reads of the launch are over now, so their positions go home
         const int nwaves = (int)gridDim.x * WV;
         float4* const x = const_cast<float4*>(p.xin);
@@ -1617,16 +1619,12 @@ __global__ void __launch_bounds__(64 * WV, MINW) step_fused(const FusedParams p)
         __builtin_amdgcn_s_waitcnt(0);   // these stores complete before the host hears of the launch (one wave: no barrier needed)
     }
     if (lane == 0) {
-        const unsigned total = p.sync[kFusedFallbacksTotal] + nfb;
-        p.sync[kFusedFallbacksTotal] = total;
+        // every result of the launch is in memory by now (see above): tell the host first, tidy up afterwards
+        if (p.host_word)
+            __hip_atomic_store(p.host_word, (unsigned long long)p.done_value | ((unsigned long long)nfb << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(p.sync + kFusedReaders, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(p.sync + kFusedFinished, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(p.sync + kFusedFallbacks, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (p.host_word) {   // every result of the launch is in memory by now (see above): tell the host
-            __hip_atomic_store(const_cast<unsigned*>(p.host_word) + 1, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __builtin_amdgcn_s_waitcnt(0);   // the count before the word the host waits for
-            __hip_atomic_store(const_cast<unsigned*>(p.host_word), p.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        if (nfb) p.sync[kFusedFallbacksTotal] += nfb;
     }
 }
 
