@@ -80,6 +80,7 @@ _SIGNATURES = {
     "nbody_ctx_set_symmetric_shape": (C.c_int, [_p, C.c_int, C.c_int]),
     "nbody_ctx_set_symmetric_runs": (C.c_int, [_p, C.c_int]),
     "nbody_ctx_autotune": (C.c_int, [_p, _p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "nbody_ctx_autotuned": (C.c_int, [_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "nbody_ctx_set_fused": (C.c_int, [_p, C.c_int]),
     "nbody_ctx_set_fused_inplace": (C.c_int, [_p, C.c_int]),
     "nbody_ctx_fused_inplace_stats": (C.c_int, [_p, C.POINTER(C.c_ulonglong)]),

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -116,6 +117,9 @@ struct nbody_ctx {
     unsigned fdone_seq = 0;            // value the last armed launch writes
     bool fdone_armed = false;          // the last fused launch writes fhost[0] = fdone_seq at its end
     bool want_host_done = false;       // nbody_simulate: arm the next in-place launch
+    // nbody_simulate near a built-in switch-over size: the decompositions measured once per size on this device (nbody.h)
+    struct Tuned { int choice; int fused, sym_runs, sym_bpl, sym_waves; double us_builtin, us_best; };
+    std::map<int, Tuned> tuned;
     unsigned long long ws_tag = 0;     // which balanced-run layout the `slabs` workspace is cleared for (0 = none: any other user of it)
     bool ws_fail_above_limit = false;  // test hook: allocations above ws_limit are attempted and FAIL (out of memory) instead of
                                // being avoided by the shape choice
@@ -315,17 +319,22 @@ void sym_square_params(nbk::SymParams* sp, const float4* x, int i0, int n, const
 
 // Block shape for the symmetric evaluation of TWO disjoint ranges (ni x nj bodies): the cheapest by the same estimate
 // (padding of both sides to whole blocks included through the task count).
-bool sym_resolve_cross(const nbody_ctx* c, int ni, int nj, SymShape* out, int* nbj)
+// `hopeless` (optional): set when no candidate could ever apply to ni targets however short the source run is made (a shape
+// request that matches nothing built, or too many target blocks) — as opposed to a workspace over the cap, which fewer sources cure.
+bool sym_resolve_cross(const nbody_ctx* c, int ni, int nj, SymShape* out, int* nbj, bool* hopeless = nullptr)
 {
     int pick = -1;
     double best = 0.0;
     int rw, rb;
     fp32_shape_request(c, &rw, &rb);
+    if (hopeless) *hopeless = true;
     for (int k = 0; k < kSymCands; ++k) {
         if ((rw && kSymCand[k][0] != rw) || (rb && kSymCand[k][1] != rb)) continue;
         const long B = 64L * kSymCand[k][0] * kSymCand[k][1];
         const long bi = (ni + B - 1) / B, bj = (nj + B - 1) / B;
-        if (bi > kSymMaxSlabs || bj > 4 * kSymMaxSlabs) continue;
+        if (bi > kSymMaxSlabs) continue;
+        if (hopeless) *hopeless = false;       // this shape takes the targets: a shorter source run may fit
+        if (bj > 4 * kSymMaxSlabs) continue;
         if (((size_t)bj * (size_t)ni + (size_t)bi * (size_t)nj) * sizeof(float4) > c->ws_cap) continue;
         const double cost = sym_cost(kSymCand[k][0], kSymCand[k][1], bi * bj, ((double)bj * ni + (double)bi * nj) * sizeof(float4), c->num_cu);
         if (pick < 0 || cost < best) { pick = k; best = cost; }
@@ -1554,26 +1563,29 @@ int nbody_accel_cross(nbody_ctx* c, const nbody_float4* d_bodies, int n_total, n
     // The workspace is nbj I-side slabs of ni bodies + nbi J-side slabs of the run. When it exceeds the cap (or cannot be
     // allocated) the source run is cut into pieces that are evaluated one after the other, the I-side sums accumulating:
     // same pair arithmetic, a smaller footprint per launch.
+    // The block shape is resolved ONCE, for a whole piece, and the workspace allocated for it before the first launch: the short
+    // last piece reuses the shape with fewer source blocks, so nothing can fail once sums have started to accumulate.
     int pieces = 1;
+    SymShape y{};
+    int nbj_full = 0;
     for (;; pieces *= 2) {
         const int per = (count + pieces - 1) / pieces;
-        SymShape y{};
-        int nbj = 0;
-        if (sym_resolve_cross(c, ni, per, &y, &nbj)) {
-            const int rc = ensure_xslabs(c, ((size_t)nbj * ni + (size_t)y.nb * per) * sizeof(float4));
+        bool hopeless = false;
+        if (sym_resolve_cross(c, ni, per, &y, &nbj_full, &hopeless)) {
+            const int rc = ensure_xslabs(c, ((size_t)nbj_full * ni + (size_t)y.nb * per) * sizeof(float4));
             if (rc == NBODY_OK) break;
             if (rc != NBODY_ERR_NOMEM) return rc;
+        } else if (hopeless) {   // not a question of workspace: no built shape takes these targets (explicit shape request, block-count limit)
+            return fail(NBODY_ERR_CONFIG, "no symmetric kernel shape for %d targets x %d sources (shape request %dx%d)", ni, count, c->sym_waves, c->sym_bpl);
         }
         if (per <= 64) return fail(NBODY_ERR_NOMEM, "no workspace for the symmetric evaluation of %d x %d bodies even in pieces of %d sources", ni, count, per);
     }
     const int per = (count + pieces - 1) / pieces;
     for (int q = 0, done = 0; done < count; ++q, done += per) {
         const int cnt = count - done < per ? count - done : per;
-        SymShape y{};
-        int nbj = 0;
-        if (!sym_resolve_cross(c, ni, cnt, &y, &nbj)) return fail(NBODY_ERR_CONFIG, "no symmetric kernel shape for %d x %d bodies", ni, cnt);
-        const size_t islabs = (size_t)nbj * ni, jslabs = (size_t)y.nb * cnt;
-        if (int rc = ensure_xslabs(c, (islabs + jslabs) * sizeof(float4))) return rc;
+        const int nbj = (cnt + y.block - 1) / y.block;       // <= nbj_full: the footprint below fits what was allocated
+        y.grid = y.nb * nbj;
+        const size_t islabs = (size_t)nbj * ni;               // then y.nb J-side slabs of cnt bodies
         nbk::SymParams sp{};
         sp.x = reinterpret_cast<const float4*>(d_bodies);
         sp.slabs_i = static_cast<float4*>(c->xslabs);
@@ -1768,17 +1780,24 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
         }
     }
     const bool graphable = !c->timing && (c->use_graph == 1 || (c->use_graph < 0 && n <= kGraphMaxN));
-    // equal-mass path of the symmetric kernels: one scan per call (the integrate carries the masses through unchanged). Not under
-    // graph capture (the generation number would be frozen into the graph). Same size rule as nbody_accel_range, so that a step
-    // and the accel + integrate pair it is made of keep giving the same bits.
-    if ((bal || runs || sym) && !(graphable && steps >= kGraphChunk)) {
+    // equal-mass path of the symmetric kernels: one scan per call and one more every kEqRescanSteps steps of a long call (the
+    // integrate carries the masses through unchanged; the scan's coordinate bound of 1e15 leaves a factor of 1000 before a padding
+    // lane at 1e18 could contribute anything but an exact zero, and no body crosses that in a thousand steps). A context with graph
+    // replay switched ON never takes the path — whatever the number of steps of the call, so that run(k) and k x run(1) give the same
+    // bits (the generation number would be frozen into a captured graph). Same size rule as nbody_accel_range, so that a step and
+    // the accel + integrate pair it is made of keep giving the same bits.
+    constexpr int kEqRescanSteps = 1024;
+    const bool eq_path = (bal || runs || sym) && !graphable;
+    auto scan_masses = [&]() -> int {
         const nbk::MassInfo* q = nullptr;
         unsigned int gen = 0;
         if (int rc = eq_scan(c, 0, reinterpret_cast<const float4*>(d_bodies), 0, n, 0, 0, 0, &q, &gen)) return rc;
         bp.eqm = q; bp.eq_gen = gen;
         rp.eqm = q; rp.eq_gen = gen;
         sp.eqm = q; sp.eq_gen = gen;
-    }
+        return NBODY_OK;
+    };
+    if (eq_path) if (int rc = scan_masses()) return rc;
     const int iblocks = (n + nbk::kWG - 1) / nbk::kWG;
     // one step = one force launch + one integrate launch, both checked
     auto enqueue_step = [&](bool timed) -> int {
@@ -1827,20 +1846,23 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
         }
         for (; k + kGraphChunk <= steps; k += kGraphChunk) HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
     }
-    for (; k < steps; ++k)
+    for (; k < steps; ++k) {
+        if (eq_path && k > 0 && k % kEqRescanSteps == 0) if (int rc = scan_masses()) return rc;
         if (int rc = enqueue_step(true)) return rc;
+    }
     return NBODY_OK;
 }
 
-// Measures the decompositions that apply to whole steps of n bodies on THIS device and leaves the context's knobs (fused step,
-// runs mode, bodies per lane) on the fastest: the switch-over sizes compiled into the library were measured on one pool of
-// MI355X boxes with one compiler; a different chip or ROCm release may move them.
-int nbody_ctx_autotune(nbody_ctx* c, const nbody_float4* d_bodies, int n, int steps_per_trial, int* out_choice, double* out_us_per_step)
+namespace {
+
+struct TuneKnobs { int fused, sym_runs, sym_bpl, sym_waves; };
+
+// Times whole steps of n bodies (scratch copies, dt = 0) under every decomposition that applies and returns the fastest. With
+// `keep_builtin_within` > 0 the context's CURRENT knobs are measured first as candidate 0 and kept unless another candidate is
+// faster by more than that fraction (so that timing noise cannot flip a choice between two runs of the same program).
+int tune_measure(nbody_ctx* c, const nbody_float4* d_bodies, int n, int steps_per_trial, double keep_builtin_within, int* out_choice,
+                 TuneKnobs* out_knobs, double* out_us_best, double* out_us_builtin)
 {
-    if (int rc = check_ctx(c)) return rc;
-    if (n < 1 || steps_per_trial < 1 || !d_bodies) return fail(NBODY_ERR_INVALID, "bad autotune arguments");
-    if (c->kernel != NBODY_KERNEL_FAST) return fail(NBODY_ERR_CONFIG, "autotune chooses among the FAST kernel's decompositions");
-    ON_DEVICE(c);
     const size_t bytes = (size_t)n * sizeof(float4);
     float4 *xs = nullptr, *vs = nullptr, *as = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1857,26 +1879,30 @@ int nbody_ctx_autotune(nbody_ctx* c, const nbody_float4* d_bodies, int n, int st
         cleanup();
         return fail(NBODY_ERR_NOMEM, "autotune: cannot allocate scratch state for %d bodies", n);
     }
-    struct Knobs { int fused, sym_runs, sym_bpl, sym_waves; };
-    const Knobs saved{c->fused, c->sym_runs, c->sym_bpl, c->sym_waves};
+    const TuneKnobs saved{c->fused, c->sym_runs, c->sym_bpl, c->sym_waves};
     const float saved_dt = c->dt;
     const bool saved_timing = c->timing;
+    const int saved_inplace = c->fused_inplace;
     c->dt = 0.0f;          // the trial steps leave the scratch positions where they are
     c->timing = false;
-    // choice id: 1 fused step, 2x balanced runs with x bodies per lane (24, 28, 210), 3 unit runs, 4 block pairs / two-kernel one-sided
-    struct Cand { int id; Knobs k; };
-    const Cand cands[] = {{1, {1, -1, 0, 0}}, {24, {0, 2, 4, 0}}, {28, {0, 2, 8, 0}}, {210, {0, 2, 10, 0}}, {3, {0, 1, 0, 0}}, {4, {0, 0, 0, 0}}};
-    int best = 0;
-    double best_us = 0.0;
-    Knobs best_k = saved;
+    c->fused_inplace = 0;  // queued trial steps: the two-array kernel, as nbody_step runs them
+    // choice id: 0 the knobs as they were, 1 fused step, 2x balanced runs with x bodies per lane (24, 28, 210), 3 unit runs, 4 block pairs / two-kernel one-sided
+    struct Cand { int id; TuneKnobs k; };
+    const Cand cands[] = {{0, saved}, {1, {1, -1, 0, 0}}, {24, {0, 2, 4, 0}}, {28, {0, 2, 8, 0}}, {210, {0, 2, 10, 0}}, {3, {0, 1, 0, 0}}, {4, {0, 0, 0, 0}}};
+    int best = -1;
+    double best_us = 0.0, builtin_us = 0.0;
+    TuneKnobs best_k = saved;
     int rc = NBODY_OK;
     for (const Cand& cd : cands) {
+        if (cd.id == 0 && keep_builtin_within <= 0.0) continue;
         if (cd.id == 1 && n > 65536) continue;                      // the one-sided fused step cannot win there; do not spend seconds on it
         c->fused = cd.k.fused; c->sym_runs = cd.k.sym_runs; c->sym_bpl = cd.k.sym_bpl; c->sym_waves = cd.k.sym_waves;
         int kind = 0;
         if (nbody_ctx_step_info(c, n, &kind, nullptr, nullptr, nullptr, nullptr) != NBODY_OK) continue;
-        const int want = cd.id == 1 ? -1 : cd.id >= 24 ? 3 : cd.id == 3 ? 2 : kind;   // the decomposition the knobs were meant to select
-        if (kind != want || (cd.id == 4 && kind != 0 && kind != 1)) continue;          // does not apply at this size
+        if (cd.id != 0) {
+            const int want = cd.id == 1 ? -1 : cd.id >= 24 ? 3 : cd.id == 3 ? 2 : kind;   // the decomposition the knobs were meant to select
+            if (kind != want || (cd.id == 4 && kind != 0 && kind != 1)) continue;          // does not apply at this size
+        }
         if (hipMemcpyAsync(xs, d_bodies, bytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
             hipMemsetAsync(vs, 0, bytes, c->stream) != hipSuccess) { rc = fail(NBODY_ERR_HIP, "autotune: scratch setup failed"); break; }
         rc = nbody_step(c, reinterpret_cast<nbody_float4*>(xs), reinterpret_cast<nbody_float4*>(as), reinterpret_cast<nbody_float4*>(vs), n, 4);   // warm-up, workspace
@@ -1893,18 +1919,70 @@ int nbody_ctx_autotune(nbody_ctx* c, const nbody_float4* d_bodies, int n, int st
             if (t < us) us = t;
         }
         if (rc != NBODY_OK) break;
-        if (best == 0 || us < best_us) { best = cd.id; best_us = us; best_k = cd.k; }
+        if (cd.id == 0) builtin_us = us;
+        const double bar = (best == 0) ? best_us * (1.0 - keep_builtin_within) : best_us;   // the built-in choice is only beaten clearly
+        if (best < 0 || us < bar) { best = cd.id; best_us = us; best_k = cd.k; }
     }
     c->dt = saved_dt;
     c->timing = saved_timing;
-    const Knobs fin = (rc == NBODY_OK && best != 0) ? best_k : saved;
-    c->fused = fin.fused; c->sym_runs = fin.sym_runs; c->sym_bpl = fin.sym_bpl; c->sym_waves = fin.sym_waves;
+    c->fused_inplace = saved_inplace;
+    c->fused = saved.fused; c->sym_runs = saved.sym_runs; c->sym_bpl = saved.sym_bpl; c->sym_waves = saved.sym_waves;
     (void)hipStreamSynchronize(c->stream);
     cleanup();
     if (rc != NBODY_OK) return rc;
-    if (best == 0) return fail(NBODY_ERR_CONFIG, "autotune: no decomposition ran for %d bodies", n);
+    if (best < 0) return fail(NBODY_ERR_CONFIG, "autotune: no decomposition ran for %d bodies", n);
+    *out_choice = best;
+    *out_knobs = best_k;
+    *out_us_best = best_us;
+    if (out_us_builtin) *out_us_builtin = builtin_us;
+    return NBODY_OK;
+}
+
+
+// Is n within a quarter of one of the built-in switch-over sizes (measured on one pool of MI355X boxes with one compiler)?
+bool near_switch_over(int n)
+{
+    for (const int s : {kFusedMaxAuto, kBalMaxAuto, kRunsMaxAuto})
+        if ((double)n >= 0.75 * s && (double)n <= 1.25 * s) return true;
+    return false;
+}
+
+bool autotune_disabled()
+{
+    static const bool off = [] { const char* e = std::getenv("NBODY_NO_AUTOTUNE"); return e && *e && *e != '0'; }();
+    return off;
+}
+
+}  // namespace
+
+// Measures the decompositions that apply to whole steps of n bodies on THIS device and leaves the context's knobs (fused step,
+// runs mode, bodies per lane) on the fastest: the switch-over sizes compiled into the library were measured on one pool of
+// MI355X boxes with one compiler; a different chip or ROCm release may move them.
+int nbody_ctx_autotune(nbody_ctx* c, const nbody_float4* d_bodies, int n, int steps_per_trial, int* out_choice, double* out_us_per_step)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (n < 1 || steps_per_trial < 1 || !d_bodies) return fail(NBODY_ERR_INVALID, "bad autotune arguments");
+    if (c->kernel != NBODY_KERNEL_FAST) return fail(NBODY_ERR_CONFIG, "autotune chooses among the FAST kernel's decompositions");
+    ON_DEVICE(c);
+    int best = 0;
+    TuneKnobs k{};
+    double us = 0.0;
+    if (int rc = tune_measure(c, d_bodies, n, steps_per_trial, 0.0, &best, &k, &us, nullptr)) return rc;
+    c->fused = k.fused; c->sym_runs = k.sym_runs; c->sym_bpl = k.sym_bpl; c->sym_waves = k.sym_waves;
     if (out_choice) *out_choice = best;
-    if (out_us_per_step) *out_us_per_step = best_us;
+    if (out_us_per_step) *out_us_per_step = us;
+    return NBODY_OK;
+}
+
+// What nbody_simulate() found when it measured whole steps of n bodies on this context (see nbody.h). choice 0 = the built-in
+// decomposition was kept; -1 = this size has not been measured (not near a switch-over, NBODY_NO_AUTOTUNE, explicit knobs, or no call yet).
+int nbody_ctx_autotuned(nbody_ctx* c, int n, int* out_choice, double* out_us_builtin, double* out_us_best)
+{
+    if (int rc = check_ctx(c)) return rc;
+    const auto it = c->tuned.find(n);
+    if (out_choice) *out_choice = it == c->tuned.end() ? -1 : it->second.choice;
+    if (out_us_builtin) *out_us_builtin = it == c->tuned.end() ? 0.0 : it->second.us_builtin;
+    if (out_us_best) *out_us_best = it == c->tuned.end() ? 0.0 : it->second.us_best;
     return NBODY_OK;
 }
 
@@ -1962,9 +2040,32 @@ int nbody_simulate(nbody_float4* d_bodies, nbody_float4* d_accelerations, nbody_
     std::lock_guard<std::recursive_mutex> lk(g_default_mu);
     nbody_ctx* c = nullptr;
     if (int rc = nbody_default_ctx(&c)) return rc;
+    // Near a built-in switch-over size the decomposition is MEASURED once per size on this device (scratch copies of the caller's
+    // bodies, a few milliseconds) instead of trusted: the sizes were measured on one pool of boxes with one compiler. The built-in
+    // choice is kept unless another one is more than 3 % faster. NBODY_NO_AUTOTUNE=1, or any explicit knob, switches this off.
+    const bool knobs_default = c->kernel == NBODY_KERNEL_FAST && c->fused == -1 && c->sym_runs == -1 && c->sym_bpl == 0 && c->sym_waves == 0 &&
+                               c->tile == 0 && c->bpl == 0 && c->jsplit == 0 && c->use_graph == 0 && !c->timing;
+    if (knobs_default && n > 0 && d_bodies && !autotune_disabled() && near_switch_over(n) && !c->tuned.count(n)) {
+        ON_DEVICE(c);
+        FusedShape fs0{};
+        const double est_us = 2.0 + (double)n * n / (fused_wanted(c, n, &fs0) ? 3.2e6 : 5.5e6);   // rough step time: a trial lasts about 10 ms
+        int trial = (int)(10000.0 / est_us);
+        trial = trial < 3 ? 3 : trial > 50 ? 50 : trial;
+        int choice = 0;
+        TuneKnobs k{};
+        double us_best = 0.0, us_builtin = 0.0;
+        if (tune_measure(c, d_bodies, n, trial, 0.03, &choice, &k, &us_best, &us_builtin) == NBODY_OK)
+            c->tuned[n] = nbody_ctx::Tuned{choice, k.fused, k.sym_runs, k.sym_bpl, k.sym_waves, us_builtin, us_best};
+        else
+            c->tuned[n] = nbody_ctx::Tuned{0, c->fused, c->sym_runs, c->sym_bpl, c->sym_waves, 0.0, 0.0};   // measurement failed: the built-in choice, and do not try again
+    }
+    const auto tuned = knobs_default ? c->tuned.find(n) : c->tuned.end();
+    const bool apply = tuned != c->tuned.end() && tuned->second.choice > 0;
+    if (apply) { c->fused = tuned->second.fused; c->sym_runs = tuned->second.sym_runs; c->sym_bpl = tuned->second.sym_bpl; c->sym_waves = tuned->second.sym_waves; }
     c->want_host_done = true;    // a fused in-place step ends by writing a host-mapped word once all its results are visible
     const int rc = nbody_step(c, d_bodies, d_accelerations, d_velocity, n, 1);
     c->want_host_done = false;
+    if (apply) { c->fused = -1; c->sym_runs = -1; c->sym_bpl = 0; c->sym_waves = 0; }
     if (rc) return rc;
     // simulate() is synchronous (kernel.cu:644). Waiting for the launch's own word costs about 4 us less per call than
     // hipStreamSynchronize (profiles/r04_sync_probe_*.txt); the stream synchronisation stays as the backstop (and reports errors).

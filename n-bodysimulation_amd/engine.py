@@ -244,6 +244,37 @@ def simulate(d_bodies: torch.Tensor, d_accelerations: torch.Tensor, d_velocity: 
     check(_lib.load().nbody_simulate(_dptr(d_bodies), _dptr(d_accelerations), _dptr(d_velocity), n))
 
 
+def simulate_autotuned(n: int) -> dict:
+    """What simulate() — the default context — found when it measured whole steps of n bodies near a built-in switch-over size
+    (nbody_ctx_autotuned): choice 0 = built-in decomposition kept, -1 = not measured, else the id of nbody_ctx_autotune."""
+    lib = _lib.load()
+    h = C.c_void_p()
+    check(lib.nbody_default_ctx(C.byref(h)))
+    choice, ub, ubest = C.c_int(), C.c_double(), C.c_double()
+    check(lib.nbody_ctx_autotuned(h, n, C.byref(choice), C.byref(ub), C.byref(ubest)))
+    return {"choice": choice.value, "us_builtin": ub.value, "us_best": ubest.value}
+
+
+def force_choice(ctx: "Context", choice: int) -> None:
+    """Put a context's knobs on the decomposition with autotune id `choice` (1 fused, 24/28/210 balanced runs with 4/8/10 bodies
+    per lane, 3 unit runs, 4 block pairs or the two-kernel one-sided path; 0 or -1: leave the built-in choice)."""
+    if choice <= 0:
+        return
+    if choice == 1:
+        ctx.set_fused(1)
+        return
+    ctx.set_fused(0)
+    if choice in (24, 28, 210):
+        ctx.set_symmetric_runs(2)
+        ctx.set_symmetric_shape(0, {24: 4, 28: 8, 210: 10}[choice])
+    elif choice == 3:
+        ctx.set_symmetric_runs(1)
+    elif choice == 4:
+        ctx.set_symmetric_runs(0)
+    else:
+        raise ValueError(f"unknown decomposition id {choice}")
+
+
 def simulate_host_legacy(bodies: np.ndarray, accelerations3: np.ndarray, velocity3: np.ndarray) -> None:
     """The older snapshot's ``simulate(float4* bodies, float3* accelerations, float3* velocity, int N)``
     (Sim-Without-OpenGL-Integration/kernel.cuh:5): HOST arrays, updated in place (bodies, velocity);

@@ -710,6 +710,38 @@ def test_graph_replay_is_identical_to_eager_launches(nb, n, kernel):
         assert np.array_equal(p, q)
 
 
+def test_graph_replay_and_equal_mass_path_do_not_depend_on_call_granularity(nb):
+    """A context with graph replay ON never takes the equal-mass path, whatever the number of steps of a call: 64 steps in one call
+    (two replayed graphs of 32), as 40 + 24 (one graph + eager steps) and as 64 single-step calls give the same bits, with
+    nbody_ctx_set_equal_mass(1) asking for the scan from 4096 bodies and every body carrying 1/N."""
+    n = 10000
+    x0 = nb.engine.seeded_bodies(n, 1, 5)              # Plummer: every mass 1/N
+    outs = []
+    for calls in ((64,), (40, 24), (1,) * 64):
+        sim = nb.engine.Simulation(x0, dt=0.01, eps2=0.002)
+        sim.ctx.set_graph(1)
+        sim.ctx.set_equal_mass(1)
+        for k in calls:
+            sim.run(k)
+        outs.append(sim.state())
+        assert not sim.ctx.equal_mass_verdict()["scanned"]
+    for other in outs[1:]:
+        for p, q in zip(outs[0], other):
+            assert np.array_equal(p, q)
+    # graph replay off (the default): the path is taken, in one call or in many — and the bits agree as well
+    eq = []
+    for calls in ((64,), (1,) * 64):
+        sim = nb.engine.Simulation(x0, dt=0.01, eps2=0.002)
+        sim.ctx.set_equal_mass(1)
+        for k in calls:
+            sim.run(k)
+        eq.append(sim.state())
+        v = sim.ctx.equal_mass_verdict()
+        assert v["scanned"] and v["uniform"]
+    for p, q in zip(eq[0], eq[1]):
+        assert np.array_equal(p, q)
+
+
 def test_small_n_shapes_cover_the_chip(nb):
     ctx = nb.engine.Context()
     assert ctx.launch_info(8192, 8192)["blocks"] >= 512      # the reference's N_BODIES
@@ -1053,11 +1085,22 @@ def test_accel_cross_in_pieces_under_a_workspace_limit(nb, oracle):
             g, w = got.cpu().numpy(), want.cpu().numpy()
             assert np.abs(g - w)[:, :3].max() / np.abs(w[:, :3]).max() <= 1e-5
             assert np.all(g[:, 3] == 0)
-    # an absurd cap is an error with a message, not a crash
+    # an absurd cap is an error with a message, not a crash — "out of workspace", reported before any sum has been touched
     c3 = nb.engine.Context()
     c3.set_workspace_limit(64)
-    with pytest.raises(nb.NBodyError):
-        c3.accel_cross(x, ref_i, i0, i1, False, j0, count, ref_j)
+    keep = torch.full((i1 - i0, 4), 7.0, device="cuda")
+    with pytest.raises(nb.NBodyError) as e:
+        c3.accel_cross(x, keep, i0, i1, True, j0, count, ref_j)
+    assert e.value.code == nb._lib.ERR_NOMEM and bool((keep == 7.0).all())
+    # a shape request that no built kernel can honour for these targets is a CONFIGURATION error at once, not a halving loop that
+    # ends in "out of memory": 300000 targets in blocks of 128 bodies would need 2344 target blocks (limit 2048)
+    big = torch.zeros((300064, 4), device="cuda")
+    c4 = nb.engine.Context()
+    c4.set_symmetric_shape(1, 2)
+    out_i, out_j = torch.zeros((300000, 4), device="cuda"), torch.zeros((64, 4), device="cuda")
+    with pytest.raises(nb.NBodyError) as e:
+        c4.accel_cross(big, out_i, 0, 300000, False, 300000, 64, out_j)
+    assert e.value.code == nb._lib.ERR_CONFIG
 
 
 def test_fp64_only_shape_request_is_auto_for_fp32(nb, oracle):
@@ -1295,12 +1338,44 @@ def test_simulate_takes_the_in_place_step_and_its_host_word(nb, oracle):
         for k in range(1, 8):
             nb.engine.simulate(x, a, v)
             got = (x.cpu().numpy(), v.cpu().numpy(), a.cpu().numpy())    # straight after the call returns
+            if k == 1:     # near a switch-over size simulate() measures the decompositions first: the comparison run follows its choice
+                nb.engine.force_choice(ref.ctx, nb.engine.simulate_autotuned(n)["choice"])
             ref.run(1)
             for p, q in zip(ref.state(), got):
                 assert np.array_equal(p, q), (n, k)
     xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
     oracle.step_jacobi(xo, ao, vo, dt=0.1, eps2=0.002, steps=7)
     assert np.abs(got[0] - xo)[:, :3].max() / 1e5 <= 1e-6
+
+
+def test_simulate_measures_the_decompositions_near_a_switch_over_size(nb, oracle):
+    """nbody_simulate() on the default context: the first call with n within a quarter of a built-in switch-over size (8192, 45056,
+    160000) times the decompositions on scratch copies and keeps the built-in one unless another is more than 3 % faster; sizes
+    elsewhere are not measured; the caller's bodies are only read by the measurement; what simulate() then computes is bit-identical
+    to a context forced onto the reported decomposition."""
+    dev = torch.device("cuda", 0)
+    for n, near in ((9000, True), (3000, False), (40000, True), (70000, False)):
+        x0 = nb.engine.seeded_bodies(n, 0, 123)
+        x = torch.from_numpy(x0).to(dev)
+        v, a = torch.zeros_like(x), torch.zeros_like(x)
+        nb.engine.simulate(x, a, v)
+        r = nb.engine.simulate_autotuned(n)
+        if near:
+            assert r["choice"] in (0, 1, 24, 28, 210, 3, 4) and r["us_builtin"] > 0 and 0 < r["us_best"] <= r["us_builtin"], (n, r)
+            if r["choice"] != 0:
+                assert r["us_best"] < 0.97 * r["us_builtin"], r      # the built-in choice is only overridden by a clear win
+        else:
+            assert r["choice"] == -1 and r["us_best"] == 0.0, (n, r)
+        nb.engine.simulate(x, a, v)
+        ref = nb.engine.Simulation(x0)                                # defaults of constants.h, like simulate()
+        nb.engine.force_choice(ref.ctx, r["choice"])
+        ref.run(2)
+        for p, q in zip(ref.state(), (x.cpu().numpy(), v.cpu().numpy(), a.cpu().numpy())):
+            assert np.array_equal(p, q), (n, r)
+        xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
+        if n <= 9000:
+            oracle.step_jacobi(xo, ao, vo, dt=0.1, eps2=0.002, steps=2)
+            assert np.abs(x.cpu().numpy() - xo)[:, :3].max() / 1e5 <= 1e-6
 
 
 def test_autotune_measures_and_sets_the_knobs(nb, oracle):
