@@ -71,6 +71,7 @@ class Comm(C.Structure):          # nbody_comm
 _p = C.c_void_p
 _SIGNATURES = {
     "nbody_simulate": (C.c_int, [_p, _p, _p, C.c_int]),
+    "nbody_simulate_prepare": (C.c_int, [_p, C.c_int]),
     "nbody_simulate_host_legacy": (C.c_int, [_p, _p, _p, C.c_int]),
     "nbody_default_ctx": (C.c_int, [C.POINTER(_p)]),
     "nbody_ctx_create": (C.c_int, [C.POINTER(_p), C.c_int]),

@@ -39,6 +39,9 @@ int main(int argc, char** argv)
     OK(nbody_default_ctx(&ctx));
     auto X = (nbody_float4*)dx; auto V = (nbody_float4*)dv; auto A = (nbody_float4*)da;
     OK(nbody_step(ctx, X, A, V, n, 50)); OK(nbody_ctx_sync(ctx));
+    OK(nbody_simulate_prepare(X, n));   // simulate()'s one-off work (near a switch-over size: the measurement of the decompositions)
+    { int choice = -1; double ub = 0, ubest = 0; OK(nbody_ctx_autotuned(ctx, n, &choice, &ub, &ubest));
+      std::printf("simulate() at N=%d: decomposition measured: choice %d (0 = built-in kept, -1 = not measured), built-in %.2f us, best %.2f us per queued step\n", n, choice, ub, ubest); }
     auto report = [&](const char* what, double secs, int steps) { std::printf("N=%d  %-58s %8.2f us/step\n", n, what, secs / steps * 1e6); };
     const int modes[] = {0, -1, 1, 0, -1, 1};
     for (int mode : modes) {
