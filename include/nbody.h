@@ -222,6 +222,9 @@ int nbody_ctx_autotune(nbody_ctx* ctx, const nbody_float4* d_bodies, int n, int 
  * environment, or as soon as any shape knob of the default context is set. nbody_ctx_autotuned reports what was found for n:
  * choice as above, 0 = built-in kept, -1 = not measured; the two timings in microseconds per step. */
 int nbody_ctx_autotuned(nbody_ctx* ctx, int n, int* out_choice, double* out_us_builtin, double* out_us_best);
+/* Pins what nbody_simulate() uses for n bodies instead of measuring (a caller that wants the same decomposition, hence the same
+ * low-order bits, on every machine): choice 0 = built-in, an id of nbody_ctx_autotune = that decomposition, -1 = forget n. */
+int nbody_ctx_set_autotuned(nbody_ctx* ctx, int n, int choice);
 
 /* Pre-size the slab workspace for up to n_targets bodies so later calls never allocate. */
 int nbody_ctx_reserve(nbody_ctx* ctx, int n_targets);
@@ -349,6 +352,18 @@ int nbody_comm_rccl_unique_id(void* out_128_bytes);
 /* The communicator is created on `device` (< 0: the calling thread's current device). */
 int nbody_comm_rccl_create(nbody_comm* out, int rank, int world, const void* unique_id_128_bytes, int device);
 int nbody_comm_rccl_destroy(nbody_comm* comm);
+
+/* The two collectives WITHOUT RCCL, for ranks that are threads of ONE process (nbody_headless --ngpu G --transport local): every rank
+ * pulls its peers' blocks with hipMemcpyPeerAsync — straight over xGMI where peer access exists — ordered by events the owning rank
+ * records and a host rendezvous of the rank threads per collective. One group per job, one communicator per rank; the ranks may
+ * share a device (rehearsals on a one-GPU box). A rank that fails calls nbody_comm_local_abort so that its peers' collectives
+ * return an error instead of waiting; a rendezvous that is not completed within deadline_seconds (<= 0: 600) does the same. */
+typedef struct nbody_local_group nbody_local_group;
+int nbody_comm_local_group_create(nbody_local_group** out, int world, double deadline_seconds);
+int nbody_comm_local_group_destroy(nbody_local_group* group);   /* after every rank's nbody_comm_local_destroy */
+int nbody_comm_local_create(nbody_comm* out, nbody_local_group* group, int rank, int device);
+int nbody_comm_local_destroy(nbody_comm* comm);
+int nbody_comm_local_abort(nbody_local_group* group);
 
 typedef struct nbody_shard nbody_shard;
 

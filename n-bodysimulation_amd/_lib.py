@@ -81,6 +81,7 @@ _SIGNATURES = {
     "nbody_ctx_set_symmetric_shape": (C.c_int, [_p, C.c_int, C.c_int]),
     "nbody_ctx_set_symmetric_runs": (C.c_int, [_p, C.c_int]),
     "nbody_ctx_autotune": (C.c_int, [_p, _p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "nbody_ctx_set_autotuned": (C.c_int, [_p, C.c_int, C.c_int]),
     "nbody_ctx_autotuned": (C.c_int, [_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "nbody_ctx_set_fused": (C.c_int, [_p, C.c_int]),
     "nbody_ctx_set_fused_inplace": (C.c_int, [_p, C.c_int]),
@@ -113,6 +114,11 @@ _SIGNATURES = {
     "nbody_shard_step": (C.c_int, [_p, C.c_int]),
     "nbody_shard_step_phase": (C.c_int, [_p, C.c_int]),
     "nbody_shard_sync": (C.c_int, [_p]),
+    "nbody_comm_local_group_create": (C.c_int, [C.POINTER(_p), C.c_int, C.c_double]),
+    "nbody_comm_local_group_destroy": (C.c_int, [_p]),
+    "nbody_comm_local_create": (C.c_int, [C.POINTER(Comm), _p, C.c_int, C.c_int]),
+    "nbody_comm_local_destroy": (C.c_int, [C.POINTER(Comm)]),
+    "nbody_comm_local_abort": (C.c_int, [_p]),
     "nbody_shard_comm_timing": (C.c_int, [_p, C.c_int]),
     "nbody_shard_set_comm_priority": (C.c_int, [_p, C.c_int]),
     "nbody_shard_comm_report": (C.c_int, [_p, C.POINTER(C.c_int)] + [C.POINTER(C.c_double)] * 4),

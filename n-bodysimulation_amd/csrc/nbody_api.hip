@@ -1981,6 +1981,28 @@ int nbody_ctx_autotune(nbody_ctx* c, const nbody_float4* d_bodies, int n, int st
     return NBODY_OK;
 }
 
+// Pins the decomposition nbody_simulate() uses for n bodies on this context, as a measurement would have: choice 0 = the built-in
+// one, an id of nbody_ctx_autotune = that decomposition, -1 = forget n (the next eligible call measures again).
+int nbody_ctx_set_autotuned(nbody_ctx* c, int n, int choice)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (n < 1) return fail(NBODY_ERR_INVALID, "n=%d", n);
+    if (choice == -1) { c->tuned.erase(n); return NBODY_OK; }
+    nbody_ctx::Tuned t{choice, -1, -1, 0, 0, 0.0, 0.0};
+    switch (choice) {
+        case 0: break;
+        case 1: t.fused = 1; break;
+        case 24: t.fused = 0; t.sym_runs = 2; t.sym_bpl = 4; break;
+        case 28: t.fused = 0; t.sym_runs = 2; t.sym_bpl = 8; break;
+        case 210: t.fused = 0; t.sym_runs = 2; t.sym_bpl = 10; break;
+        case 3: t.fused = 0; t.sym_runs = 1; break;
+        case 4: t.fused = 0; t.sym_runs = 0; break;
+        default: return fail(NBODY_ERR_CONFIG, "unknown decomposition id %d (0, 1, 24, 28, 210, 3, 4)", choice);
+    }
+    c->tuned[n] = t;
+    return NBODY_OK;
+}
+
 // What nbody_simulate() found when it measured whole steps of n bodies on this context (see nbody.h). choice 0 = the built-in
 // decomposition was kept; -1 = this size has not been measured (not near a switch-over, NBODY_NO_AUTOTUNE, explicit knobs, or no call yet).
 int nbody_ctx_autotuned(nbody_ctx* c, int n, int* out_choice, double* out_us_builtin, double* out_us_best)

@@ -9,7 +9,9 @@
 //   (results discarded, no timing)                  D2H, --dump state, timing, one JSON line
 //   cudaFree / cudaFreeHost                         nbody_free_*                                   (:358-366)
 //   device 0 only (kernel.cu:630, main.cpp:287)     --ngpu G: G ranks in this process (one thread and one GPU each) over
-//                                                   nbody_shard_* + nbody_comm_rccl_* (RCCL all-gather / exchange)
+//                                                   nbody_shard_* + nbody_comm_rccl_* (RCCL all-gather / exchange), or
+//                                                   --transport local: nbody_comm_local_* (hipMemcpyPeerAsync pulls between the
+//                                                   rank threads, no RCCL; --share-devices: more ranks than GPUs, a rehearsal)
 //   fp32 only                                       --precision f64: the build's double variant (nbody_step_f64, 1 GPU)
 //
 // State files (--dump P / --load P): P.json {n, steps_done, dt, eps2} + P.x.f4 / P.v.f4 / P.a.f4,
@@ -61,6 +63,8 @@ static bool read_file(const std::string& path, void* p, size_t bytes)
 int main(int argc, char** argv)
 {
     int n = N_BODIES, steps = 10, kernel = NBODY_KERNEL_FAST, sync_each = 0, interactive = 0, json = 1, ngpu = 1, timeout_s = 900, autotune = 0, equal_mass = -1;
+    std::string transport = "rccl";   // --ngpu: rccl (librccl, one GPU per rank) | local (hipMemcpyPeerAsync pulls between the rank threads, no RCCL)
+    bool share_devices = false;
     bool f64 = false, force_shard = false;
     long steps_done = 0;
     float dt = DT, eps2 = EPS2;
@@ -81,6 +85,8 @@ int main(int argc, char** argv)
                      : k == "symmetric" ? NBODY_KERNEL_SYMMETRIC : NBODY_KERNEL_FAST;
         }
         else if (a == "--ngpu") ngpu = std::atoi(val());
+        else if (a == "--transport") { transport = val(); if (transport != "rccl" && transport != "local") die("--transport rccl|local"); }
+        else if (a == "--share-devices") share_devices = true;   // --transport local only: more ranks than GPUs, rank r on device r % ndev (rehearsal)
         else if (a == "--timeout") timeout_s = std::atoi(val());   // --ngpu: seconds before a stalled collective is given up (0 = wait for ever)
         else if (a == "--shard") force_shard = true;     // run through nbody_shard_* + RCCL even with one GPU
         else if (a == "--precision") { std::string q = val(); if (q != "f32" && q != "f64") die("--precision f32|f64"); f64 = q == "f64"; }
@@ -92,7 +98,7 @@ int main(int argc, char** argv)
         else if (a == "--interactive") interactive = 1;
         else if (a == "--quiet") json = 0;
         else die("unknown option " + a + "\nusage: nbody_headless [--n N] [--steps K] [--dt f] [--eps2 f] [--init libc|ref|plummer] [--seed S]"
-                 " [--kernel fast|strict|onesided|symmetric] [--autotune] [--no-equal-mass] [--ngpu G] [--timeout S] [--shard] [--precision f32|f64] [--dump P] [--load P] [--sync-each-step]"
+                 " [--kernel fast|strict|onesided|symmetric] [--autotune] [--no-equal-mass] [--ngpu G] [--transport rccl|local] [--share-devices] [--timeout S] [--shard] [--precision f32|f64] [--dump P] [--load P] [--sync-each-step]"
                  " [--interactive]");
     }
     if (interactive) {
@@ -144,9 +150,14 @@ int main(int argc, char** argv)
         // G ranks in this process: one thread, one device, one context, one RCCL communicator and one shard each
         int ndev = 0;
         ok(nbody_device_count(&ndev));
-        if (ngpu > ndev) die("--ngpu " + std::to_string(ngpu) + " but only " + std::to_string(ndev) + " device(s) visible");
+        const bool local = transport == "local";
+        if (share_devices && !local) die("--share-devices needs --transport local (RCCL refuses two ranks on one device)");
+        if (ngpu > ndev && !share_devices) die("--ngpu " + std::to_string(ngpu) + " but only " + std::to_string(ndev) + " device(s) visible");
+        if (ndev < 1) die("no device");
         char uid[128];
-        ok(nbody_comm_rccl_unique_id(uid));
+        nbody_local_group* group = nullptr;
+        if (local) ok(nbody_comm_local_group_create(&group, ngpu, timeout_s > 0 ? (double)timeout_s : 0.0));
+        else ok(nbody_comm_rccl_unique_id(uid));
         // Every step that can fail LOCALLY (device, context, allocations) is taken before a collective one, and the ranks
         // agree on success at a gate before entering it: a rank that failed never leaves its peers waiting inside
         // ncclCommInitRank or the first all-gather. What can still stall (a collective itself) is bounded by a deadline
@@ -182,12 +193,14 @@ int main(int argc, char** argv)
             nbody_shard* sh = nullptr;
             bool good = true;
             // 1. local: device, context
-            if (nbody_ctx_create(&ctx, r) != NBODY_OK) { note("nbody_ctx_create"); good = false; }
+            const int dev = r % ndev;
+            if (nbody_ctx_create(&ctx, dev) != NBODY_OK) { note("nbody_ctx_create"); good = false; }
             else if (nbody_ctx_set_params(ctx, dt, eps2) != NBODY_OK || nbody_ctx_set_kernel(ctx, kernel, 0, 0, 0) != NBODY_OK ||
                      nbody_ctx_set_equal_mass(ctx, equal_mass) != NBODY_OK) { note("context setup"); good = false; }
             if (gate.pass(good)) {
                 // 2. collective: the communicator (every rank enters, or none does)
-                if (nbody_comm_rccl_create(&comm, r, ngpu, uid, r) != NBODY_OK) { note("nbody_comm_rccl_create"); good = false; }
+                if (local) { if (nbody_comm_local_create(&comm, group, r, dev) != NBODY_OK) { note("nbody_comm_local_create"); good = false; } }
+                else if (nbody_comm_rccl_create(&comm, r, ngpu, uid, dev) != NBODY_OK) { note("nbody_comm_rccl_create"); good = false; }
                 // 3. local: the shard's device arrays, the upload
                 if (good && nbody_shard_create(&sh, ctx, r, ngpu, n, &comm) != NBODY_OK) { note("nbody_shard_create"); good = false; }
                 if (good && nbody_shard_upload(sh, (const nbody_float4*)bodies) != NBODY_OK) { note("nbody_shard_upload"); good = false; }
@@ -195,7 +208,11 @@ int main(int argc, char** argv)
                 // every rank has read the shared host arrays before anybody steps (and nobody writes them before the join)
                 if (gate.pass(good)) {
                     const auto t0 = std::chrono::steady_clock::now();
-                    if (nbody_shard_step(sh, steps) != NBODY_OK || nbody_shard_sync(sh) != NBODY_OK) { note("nbody_shard_step"); good = false; }
+                    if (nbody_shard_step(sh, steps) != NBODY_OK || nbody_shard_sync(sh) != NBODY_OK) {
+                        note("nbody_shard_step");
+                        good = false;
+                        if (local) nbody_comm_local_abort(group);   // peers waiting at a rendezvous give up instead of hanging
+                    }
                     rank_secs[r] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                     nbody_shard_plan_t plan;
                     if (good && nbody_shard_get_plan(sh, &plan) == NBODY_OK) {
@@ -208,7 +225,8 @@ int main(int argc, char** argv)
             }
             if (!good && errors[r].empty()) errors[r] = "skipped: another rank failed";
             if (sh) nbody_shard_destroy(sh);
-            nbody_comm_rccl_destroy(&comm);
+            if (local) nbody_comm_local_destroy(&comm);
+            else nbody_comm_rccl_destroy(&comm);
             if (ctx) nbody_ctx_destroy(ctx);
             std::lock_guard<std::mutex> lk(done_mu);
             ++done;
@@ -230,6 +248,7 @@ int main(int argc, char** argv)
             }
         }
         for (auto& t : threads) t.join();
+        if (group) nbody_comm_local_group_destroy(group);
         bool any_error = false;
         for (int r = 0; r < ngpu; ++r)
             if (!errors[r].empty() && errors[r].rfind("skipped", 0) != 0) { std::cerr << "rank " << r << ": " << errors[r] << std::endl; any_error = true; }

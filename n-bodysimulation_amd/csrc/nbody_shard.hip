@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -591,6 +593,216 @@ int nbody_comm_rccl_destroy(nbody_comm* comm)
     if (!comm || !comm->user) return NBODY_OK;
     RcclUser* u = static_cast<RcclUser*>(comm->user);
     if (u->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(u->comm);
+    delete u;
+    comm->user = nullptr;
+    comm->all_gather = nullptr;
+    comm->exchange = nullptr;
+    return NBODY_OK;
+}
+
+}  // extern "C"
+
+// ---- LOCAL transport: the ranks are threads of ONE process, each with its own device (or, for rehearsals, sharing one) ----------
+//
+// No RCCL: every rank PULLS what it needs with hipMemcpyPeerAsync (device to device over xGMI when peer access is enabled), ordered by
+// events that the owning rank records and a host rendezvous of the rank threads per collective:
+//   all-gather  each rank copies its advanced block into one of two staging buffers and records `ready`; after the rendezvous every rank
+//               waits on its peers' `ready` events and pulls their staged blocks into its own position array. Two staging buffers
+//               are enough: a rank's staging copy of step k+2 runs, by the chain of events, after every peer has finished pulling step k.
+//   exchange    each rank publishes its J-side buffer and send table and records `cross`; after the rendezvous every rank pulls the
+//               segments addressed to it from its peers' J-side buffers (which are next written after the following all-gather).
+// A rank that fails aborts the group (nbody_comm_local_abort): peers waiting at a rendezvous return an error instead of hanging, and
+// a rendezvous that nobody completes within the group's deadline does the same.
+struct nbody_local_group {
+    int world = 1;
+    double deadline_s = 600.0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int waiting = 0, generation = 0;
+    bool aborted = false;
+    struct Rank {
+        int device = -1;
+        bool attached = false;
+        float4* stage[2] = {nullptr, nullptr};
+        size_t stage_bodies = 0;
+        hipEvent_t ready[2] = {nullptr, nullptr};
+        hipEvent_t cross = nullptr;
+        const nbody_float4* jbuf = nullptr;
+        nbody_shard_segment send[NBODY_MAX_RANKS];
+        int n_sends = 0;
+        unsigned long gathers = 0;
+    } rank[NBODY_MAX_RANKS];
+
+    bool rendezvous()   // false: the group was aborted (or nobody came within the deadline)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        if (aborted) return false;
+        const int gen = generation;
+        if (++waiting == world) {
+            waiting = 0;
+            ++generation;
+            cv.notify_all();
+            return true;
+        }
+        const bool came = cv.wait_for(lk, std::chrono::duration<double>(deadline_s), [&] { return generation != gen || aborted; });
+        if (!came) { aborted = true; cv.notify_all(); }
+        return generation != gen && !aborted;
+    }
+};
+
+namespace {
+
+struct LocalUser {
+    nbody_local_group* g = nullptr;
+    int rank = 0;
+};
+
+int local_all_gather(void* user, nbody_float4* d_x_full, int bodies_per_rank, void* hip_stream)
+{
+    LocalUser* u = static_cast<LocalUser*>(user);
+    nbody_local_group* g = u->g;
+    nbody_local_group::Rank& me = g->rank[u->rank];
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const size_t bytes = (size_t)bodies_per_rank * sizeof(float4);
+    if (me.stage_bodies < (size_t)bodies_per_rank) {
+        for (int b = 0; b < 2; ++b) {
+            if (me.stage[b]) (void)hipFree(me.stage[b]);
+            me.stage[b] = nullptr;
+            if (hipMalloc(reinterpret_cast<void**>(&me.stage[b]), bytes ? bytes : 16) != hipSuccess) { nbody_comm_local_abort(g); return 1; }
+        }
+        me.stage_bodies = (size_t)bodies_per_rank;
+    }
+    const int b = (int)(me.gathers & 1);
+    float4* const x = reinterpret_cast<float4*>(d_x_full);
+    bool ok = hipMemcpyAsync(me.stage[b], x + (size_t)u->rank * bodies_per_rank, bytes, hipMemcpyDeviceToDevice, st) == hipSuccess &&
+              hipEventRecord(me.ready[b], st) == hipSuccess;
+    if (!ok) nbody_comm_local_abort(g);
+    if (!g->rendezvous()) return 1;          // everybody has staged its block and recorded its event
+    for (int q = 0; q < g->world && ok; ++q) {
+        if (q == u->rank) continue;
+        const nbody_local_group::Rank& peer = g->rank[q];
+        ok = hipStreamWaitEvent(st, peer.ready[b], 0) == hipSuccess &&
+             hipMemcpyPeerAsync(x + (size_t)q * bodies_per_rank, me.device, peer.stage[b], peer.device, bytes, st) == hipSuccess;
+    }
+    ++me.gathers;
+    if (!ok) { nbody_comm_local_abort(g); return 1; }
+    return 0;
+}
+
+int local_exchange(void* user, const nbody_shard_segment* send, int n_sends, const nbody_float4* d_jbuf,
+                   const nbody_shard_segment* recv, int n_recvs, nbody_float4* d_rbuf, void* hip_stream)
+{
+    LocalUser* u = static_cast<LocalUser*>(user);
+    nbody_local_group* g = u->g;
+    nbody_local_group::Rank& me = g->rank[u->rank];
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    me.jbuf = d_jbuf;
+    me.n_sends = n_sends < NBODY_MAX_RANKS ? n_sends : NBODY_MAX_RANKS;
+    for (int k = 0; k < me.n_sends; ++k) me.send[k] = send[k];
+    bool ok = hipEventRecord(me.cross, st) == hipSuccess;   // (the stream already waits for this rank's cross launches)
+    if (!ok) nbody_comm_local_abort(g);
+    if (!g->rendezvous()) return 1;          // everybody has published its J-side buffer, its send table and its event
+    for (int k = 0; k < n_recvs && ok; ++k) {
+        const nbody_local_group::Rank& peer = g->rank[recv[k].peer];
+        const nbody_shard_segment* src = nullptr;
+        for (int m = 0; m < peer.n_sends; ++m)
+            if (peer.send[m].peer == u->rank) src = &peer.send[m];
+        if (!src || src->count != recv[k].count || src->body0 != recv[k].body0) { ok = false; break; }   // the two plans disagree
+        ok = hipStreamWaitEvent(st, peer.cross, 0) == hipSuccess &&
+             hipMemcpyPeerAsync(d_rbuf + recv[k].offset, me.device, peer.jbuf + src->offset, peer.device,
+                                (size_t)recv[k].count * sizeof(float4), st) == hipSuccess;
+    }
+    if (!ok) { nbody_comm_local_abort(g); return 1; }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nbody_comm_local_group_create(nbody_local_group** out, int world, double deadline_seconds)
+{
+    if (!out) return nbody_fail(NBODY_ERR_INVALID, "null out");
+    *out = nullptr;
+    if (world < 1 || world > NBODY_MAX_RANKS) return nbody_fail(NBODY_ERR_INVALID, "world=%d (1..%d)", world, NBODY_MAX_RANKS);
+    nbody_local_group* g = new (std::nothrow) nbody_local_group();
+    if (!g) return nbody_fail(NBODY_ERR_NOMEM, "out of host memory");
+    g->world = world;
+    if (deadline_seconds > 0) g->deadline_s = deadline_seconds;
+    *out = g;
+    return NBODY_OK;
+}
+
+int nbody_comm_local_abort(nbody_local_group* g)
+{
+    if (!g) return NBODY_OK;
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->aborted = true;
+    g->cv.notify_all();
+    return NBODY_OK;
+}
+
+int nbody_comm_local_group_destroy(nbody_local_group* g)
+{
+    if (!g) return NBODY_OK;
+    for (int r = 0; r < g->world; ++r)
+        if (g->rank[r].attached) return nbody_fail(NBODY_ERR_INVALID, "rank %d of the local group still has its communicator", r);
+    delete g;
+    return NBODY_OK;
+}
+
+int nbody_comm_local_create(nbody_comm* out, nbody_local_group* g, int rank, int device)
+{
+    if (!out || !g) return nbody_fail(NBODY_ERR_INVALID, "null argument");
+    if (rank < 0 || rank >= g->world) return nbody_fail(NBODY_ERR_INVALID, "rank %d of %d", rank, g->world);
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) return nbody_fail(NBODY_ERR_HIP, "no current HIP device");
+    DeviceScope scope(device);
+    if (scope.err != hipSuccess) return nbody_fail(NBODY_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.err));
+    nbody_local_group::Rank& me = g->rank[rank];
+    if (me.attached) return nbody_fail(NBODY_ERR_INVALID, "rank %d of the local group already has a communicator", rank);
+    LocalUser* u = new (std::nothrow) LocalUser();
+    if (!u) return nbody_fail(NBODY_ERR_NOMEM, "out of host memory");
+    u->g = g;
+    u->rank = rank;
+    me.device = device;
+    for (hipEvent_t* e : {&me.ready[0], &me.ready[1], &me.cross})
+        if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) {
+            delete u;
+            return nbody_fail(NBODY_ERR_HIP, "hipEventCreateWithFlags failed on device %d", device);
+        }
+    // direct device-to-device copies where the hardware offers them (xGMI); refused or repeated requests are not errors
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) == hipSuccess)
+        for (int d = 0; d < ndev; ++d) {
+            int can = 0;
+            if (d != device && hipDeviceCanAccessPeer(&can, device, d) == hipSuccess && can)
+                if (hipDeviceEnablePeerAccess(d, 0) != hipSuccess) (void)hipGetLastError();
+        }
+    me.attached = true;
+    out->user = u;
+    out->all_gather = local_all_gather;
+    out->exchange = local_exchange;
+    return NBODY_OK;
+}
+
+int nbody_comm_local_destroy(nbody_comm* comm)
+{
+    if (!comm || !comm->user) return NBODY_OK;
+    LocalUser* u = static_cast<LocalUser*>(comm->user);
+    nbody_local_group::Rank& me = u->g->rank[u->rank];
+    {
+        DeviceScope scope(me.device);
+        for (int b = 0; b < 2; ++b) {
+            if (me.stage[b]) (void)hipFree(me.stage[b]);
+            if (me.ready[b]) (void)hipEventDestroy(me.ready[b]);
+            me.stage[b] = nullptr;
+            me.ready[b] = nullptr;
+        }
+        if (me.cross) (void)hipEventDestroy(me.cross);
+        me.cross = nullptr;
+        me.stage_bodies = 0;
+    }
+    me.attached = false;
     delete u;
     comm->user = nullptr;
     comm->all_gather = nullptr;

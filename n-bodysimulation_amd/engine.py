@@ -255,6 +255,14 @@ def simulate_autotuned(n: int) -> dict:
     return {"choice": choice.value, "us_builtin": ub.value, "us_best": ubest.value}
 
 
+def simulate_pin(n: int, choice: int) -> None:
+    """nbody_ctx_set_autotuned on the default context: pin what simulate() uses for n bodies (0 built-in, an autotune id, -1 forget)."""
+    lib = _lib.load()
+    h = C.c_void_p()
+    check(lib.nbody_default_ctx(C.byref(h)))
+    check(lib.nbody_ctx_set_autotuned(h, n, choice))
+
+
 def force_choice(ctx: "Context", choice: int) -> None:
     """Put a context's knobs on the decomposition with autotune id `choice` (1 fused, 24/28/210 balanced runs with 4/8/10 bodies
     per lane, 3 unit runs, 4 block pairs or the two-kernel one-sided path; 0 or -1: leave the built-in choice)."""

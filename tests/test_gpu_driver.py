@@ -108,6 +108,50 @@ def test_headless_sharded_path_over_rccl_and_f64(nb, oracle, tmp_path):
     assert json.load(open(tmp_path / "d.json"))["dtype"] == "f64"
 
 
+@pytest.mark.parametrize("ranks", [2, 3, 4, 8])
+def test_headless_rank_threads_over_the_local_transport(nb, oracle, tmp_path, ranks):
+    """nbody_headless --ngpu G with G > 1 — rank THREADS in one process, one context, one communicator and one shard each, the gates
+    between them, the per-rank downloads and the merge — executed for real: --transport local moves the data with
+    hipMemcpyPeerAsync pulls between the ranks (no RCCL, which refuses two ranks on one device) and --share-devices puts all ranks on
+    this box's one GPU. STRICT kernel (canonical schedule): bit-identical to the single-device Jacobi oracle, padding bodies included
+    (n is not a multiple of any rank count). FAST (symmetric schedule, J-side sums exchanged) and ONESIDED: within the fast tolerances
+    of it, and bit-identical from one run to the next."""
+    n, steps = 5003, 3
+    base = ["--n", str(n), "--steps", str(steps), "--init", "plummer", "--dt", "0.01", "--seed", "21", "--quiet",
+            "--ngpu", str(ranks), "--transport", "local", "--share-devices", "--timeout", "120"]
+    x0 = nb.engine.seeded_bodies(n, 1, 21)
+    xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
+    oracle.step_jacobi(xo, ao, vo, dt=0.01, eps2=0.002, steps=steps)
+    _run([DRIVER, *base, "--kernel", "strict", "--dump", str(tmp_path / "st")])
+    assert np.array_equal(_f4(tmp_path / "st.x.f4", n), xo) and np.array_equal(_f4(tmp_path / "st.v.f4", n), vo)
+    assert np.array_equal(_f4(tmp_path / "st.a.f4", n), ao)
+    for kernel in ("fast", "onesided"):
+        _run([DRIVER, *base, "--kernel", kernel, "--dump", str(tmp_path / kernel)])
+        x, a = _f4(tmp_path / f"{kernel}.x.f4", n), _f4(tmp_path / f"{kernel}.a.f4", n)
+        assert np.abs(x - xo)[:, :3].max() <= 1e-6
+        assert np.abs(a - ao)[:, :3].max() / np.abs(ao[:, :3]).max() <= 1e-5
+    _run([DRIVER, *base, "--kernel", "fast", "--dump", str(tmp_path / "again")])
+    for ext in ("x", "v", "a"):
+        assert np.array_equal(_f4(tmp_path / f"fast.{ext}.f4", n), _f4(tmp_path / f"again.{ext}.f4", n)), ext
+
+
+def test_headless_local_transport_at_the_block_sizes_a_node_runs(nb, tmp_path):
+    """Four rank threads x 65536 bodies (the default block shapes of both the own-block pass and the cross launches), two steps, so
+    that the all-gather of ADVANCED positions is exercised too: against the single-GPU run of the same system."""
+    n = 262144
+    base = ["--n", str(n), "--steps", "2", "--init", "plummer", "--dt", "0.01", "--seed", "5", "--quiet"]
+    _run([DRIVER, *base, "--dump", str(tmp_path / "one")])
+    out = _run([DRIVER, *base[:-1], "--ngpu", "4", "--transport", "local", "--share-devices", "--dump", str(tmp_path / "four")])
+    assert json.loads(out.strip().splitlines()[-1])["ngpu"] == 4
+    x1, a1 = _f4(tmp_path / "one.x.f4", n), _f4(tmp_path / "one.a.f4", n)
+    x4, a4 = _f4(tmp_path / "four.x.f4", n), _f4(tmp_path / "four.a.f4", n)
+    assert np.abs(x4 - x1)[:, :3].max() <= 1e-6
+    assert np.abs(a4 - a1)[:, :3].max() / np.abs(a1[:, :3]).max() <= 2e-5
+    # misuse is refused with a message
+    r = subprocess.run([DRIVER, "--n", "4096", "--ngpu", "2", "--share-devices"], capture_output=True, text=True)
+    assert r.returncode != 0 and "--transport local" in r.stderr
+
+
 def test_compare_host_to_device_program():
     """compareHostToDevice in the reference's own terms: lock-step GPU/CPU steps, then the 1 % rule on
     positions, velocities and accelerations."""

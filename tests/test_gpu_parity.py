@@ -1378,6 +1378,34 @@ def test_simulate_measures_the_decompositions_near_a_switch_over_size(nb, oracle
             assert np.abs(x.cpu().numpy() - xo)[:, :3].max() / 1e5 <= 1e-6
 
 
+@pytest.mark.parametrize("n,choice", [(9000, 1), (9000, 24), (9000, 28), (9000, 4), (40000, 210), (40000, 3), (40000, 4), (5000, 24)])
+def test_simulate_applies_a_pinned_decomposition_bit_for_bit(nb, n, choice):
+    """Whatever a measurement may find on some other machine, simulate() applies it exactly: with the decomposition for n pinned
+    (nbody_ctx_set_autotuned) two simulate() calls give the bits of a context forced onto that decomposition through the knobs, and
+    forgetting the pin restores the built-in choice."""
+    dev = torch.device("cuda", 0)
+    x0 = nb.engine.seeded_bodies(n, 0, 321)
+    try:
+        nb.engine.simulate_pin(n, choice)
+        assert nb.engine.simulate_autotuned(n)["choice"] == choice
+        x = torch.from_numpy(x0).to(dev)
+        v, a = torch.zeros_like(x), torch.zeros_like(x)
+        nb.engine.simulate(x, a, v)
+        nb.engine.simulate(x, a, v)
+        ref = nb.engine.Simulation(x0)
+        nb.engine.force_choice(ref.ctx, choice)
+        info = ref.ctx.step_info(n)
+        assert {1: info["fused"], 24: info["balanced"], 28: info["balanced"], 210: info["balanced"], 3: info["runs"],
+                4: not (info["fused"] or info["balanced"] or info["runs"])}[choice], info
+        ref.run(2)
+        for p, q in zip(ref.state(), (x.cpu().numpy(), v.cpu().numpy(), a.cpu().numpy())):
+            assert np.array_equal(p, q)
+    finally:
+        nb.engine.simulate_pin(n, 0 if n == 5000 else -1)
+    with pytest.raises(nb.NBodyError):
+        nb.engine.simulate_pin(n, 7)
+
+
 def test_autotune_measures_and_sets_the_knobs(nb, oracle):
     """nbody_ctx_autotune: times the decompositions that apply to whole steps of n bodies on the device at hand (scratch copies,
     dt = 0: the caller's array is only read) and leaves the context on the fastest. On MI355X that reproduces the built-in choice at
