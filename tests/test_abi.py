@@ -198,3 +198,19 @@ def test_fused_step_shape_without_a_device(nb):
         if n <= 8192:
             assert t == 2 and grid <= 256
     assert lib.nbody_plan_fused(0, 256, None, None, None, None) == nb._lib.ERR_INVALID
+
+
+def test_local_group_and_pin_arguments_without_a_device(nb):
+    """The host-only parts of the round-4 entry points: a local (rank threads, no RCCL) group is created for 1 ... 64 ranks, refused
+    outside that, destroyed once no rank holds a communicator; abort on a null group is a no-op."""
+    lib, L = nb.load(), nb._lib
+    g = C.c_void_p()
+    assert lib.nbody_comm_local_group_create(C.byref(g), 0, 0.0) == L.ERR_INVALID and not g.value
+    assert lib.nbody_comm_local_group_create(C.byref(g), L.MAX_RANKS + 1, 0.0) == L.ERR_INVALID
+    assert lib.nbody_comm_local_group_create(None, 2, 0.0) == L.ERR_INVALID
+    assert lib.nbody_comm_local_group_create(C.byref(g), 3, 5.0) == L.OK and g.value
+    assert lib.nbody_comm_local_abort(g) == L.OK and lib.nbody_comm_local_abort(None) == L.OK
+    comm = L.Comm()
+    assert lib.nbody_comm_local_create(C.byref(comm), g, 3, 0) == L.ERR_INVALID      # rank 3 of 3
+    assert lib.nbody_comm_local_destroy(C.byref(comm)) == L.OK                         # never created: nothing to do
+    assert lib.nbody_comm_local_group_destroy(g) == L.OK and lib.nbody_comm_local_group_destroy(None) == L.OK
