@@ -1655,10 +1655,12 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
     if (fused_wanted(c, n, &fs) && ensure_xalt(c, n) == NBODY_OK) {   // (no spare array to be had: the two-kernel paths below)
         // small systems: one launch per step (force + integrate). Two-array kernel: positions alternate between the caller's array
         // and a spare one, and an odd number of steps ends with a copy-back launch. In-place kernel (nbk::step_fused<.., INPLACE>): the
-        // caller's array is read and written by the same launch. Default: two-array launches in pairs, the odd last step in place.
+        // caller's array is read and written by the same launch (used by nbody_simulate, see below).
         float4* const xa = reinterpret_cast<float4*>(d_bodies);
         float4* const xb = static_cast<float4*>(c->xalt);
-        const int mode = c->timing ? 0 : c->fused_inplace;     // (instrumented runs keep the plain kernel: one event pair per launch)
+        // (instrumented runs keep the plain kernel: one event pair per launch; the in-place counter packs workgroups and fall-back waves
+        //  into 16 bits each, far beyond any size the fused step is meant for)
+        const int mode = (c->timing || (long)fs.grid * fs.wv > 65535) ? 0 : c->fused_inplace;
         // default (-1): in place only where it pays — the odd last step of a call whose caller will wait on the launch's host-mapped
         // word (nbody_simulate). Queued, the two-array kernel is 3.4 us per step faster (the in-place launch ends with a chain of
         // round trips: look at the counter, stores through the L2, count out), and a copy-back launch costs 2.1 (profiles/r04_sync_probe_*.txt).
@@ -2117,6 +2119,7 @@ int nbody_simulate(nbody_float4* d_bodies, nbody_float4* d_accelerations, nbody_
     const auto tuned = knobs_default ? c->tuned.find(n) : c->tuned.end();
     const bool apply = tuned != c->tuned.end() && tuned->second.choice > 0;
     if (apply) { c->fused = tuned->second.fused; c->sym_runs = tuned->second.sym_runs; c->sym_bpl = tuned->second.sym_bpl; c->sym_waves = tuned->second.sym_waves; }
+    c->fdone_armed = false;
     c->want_host_done = true;    // a fused in-place step ends by writing a host-mapped word once all its results are visible
     const int rc = nbody_step(c, d_bodies, d_accelerations, d_velocity, n, 1);
     c->want_host_done = false;
