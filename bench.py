@@ -257,11 +257,12 @@ def main():
     ap.add_argument("--comm", default="torch", choices=["torch", "native"], help="who runs the step's two collectives: torch = "
                     "torch.distributed on the --backend group; native = the library's own RCCL communicator (nbody_comm_rccl_*), "
                     "its unique id broadcast through the --backend group, which then only carries barriers and reductions")
-    ap.add_argument("--comm-priority", default="auto", choices=["auto", "high", "normal"], help="priority of the stream RCCL's kernels run on: normal "
+    ap.add_argument("--comm-priority", default="auto", choices=["auto", "high", "normal", "ab"], help="priority of the stream RCCL's kernels run on: normal "
                     "(the library's default), high = the device's greatest (RCCL's few workgroups are placed ahead of the queued force workgroups; "
                     "MEASURED PATHOLOGICAL when three or more processes share one GPU: profiles/r04a_rehearsal_priority_probe.txt), auto = normal, "
                     "except with --comm native on a GPU per rank, where a few untimed steps are run both ways before the timed repeats and the faster "
-                    "setting is kept (both timings reported as config.rccl.comm_priority_ab)")
+                    "setting is kept (both timings reported as config.rccl.comm_priority_ab); ab = that in-run comparison wherever the ranks run "
+                    "(--comm native only)")
     ap.add_argument("--no-single-gpu-point", action="store_true", help="multi-GPU runs: skip rank 0's same-N single-GPU timing before the sharded phase")
     ap.add_argument("--fake-hosts", action="store_true", help="rehearsal only: give every rank its own NCCL_HOSTID so that RCCL "
                     "accepts several ranks on ONE GPU (it then talks over its socket transport on the loopback interface)")
@@ -294,7 +295,9 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     ndev = torch.cuda.device_count()
     shared_gpu = args.fake_hosts or (args.backend != "nccl" and args.comm != "native")
-    comm_priority = args.comm_priority if args.comm_priority != "auto" else "normal"
+    if args.comm_priority == "ab" and args.comm != "native":
+        raise SystemExit("--comm-priority ab compares stream priorities of the library's own communicator: add --comm native")
+    comm_priority = args.comm_priority if args.comm_priority in ("high", "normal") else "normal"
     priority_ab = None
     if world > ndev and not shared_gpu:
         raise SystemExit(f"{world} ranks but {ndev} GPU(s): RCCL needs one GPU per rank (use --backend gloo, or --fake-hosts, to rehearse)")
@@ -512,7 +515,7 @@ def main():
     barrier()
 
     # ---- --comm-priority auto, library communicator, one GPU per rank: measure both settings on this machine, keep the faster ----
-    if multi and world > 1 and args.comm_priority == "auto" and args.comm == "native" and not shared_gpu:
+    if multi and world > 1 and args.comm == "native" and (args.comm_priority == "ab" or (args.comm_priority == "auto" and not shared_gpu)):
         phase("comm priority A/B")
         k_ab = max(2, min(args.steps, 5))
         ab = {}

@@ -62,6 +62,20 @@ def test_bench_multi_rank_over_real_rccl_on_one_gpu(fake_hosts, comm, world):
     assert line["config"]["comm_rank0"]["all_gather_ms_avg"] > 0 and line["config"]["comm_rank0"]["exchange_ms_avg"] > 0
 
 
+def test_bench_compares_stream_priorities_in_the_run(fake_hosts):
+    """--comm-priority ab (what `auto` does on a GPU per rank with the library's communicator): a few untimed steps at normal and at
+    the greatest stream priority, the faster kept on every rank, both timings in the line. Two ranks: the high priority is not
+    pathological there, so either outcome is legitimate; the fields and the usual self-certification are checked."""
+    line = run_bench(torchrun(2, "--fake-hosts", "--comm", "native", "--comm-priority", "ab", "--bodies", "49152", "--steps", "2", "--warmup", "2",
+                              "--repeats", "2"))
+    check_multi_gpu_line(line, 2, 49152, "native", distinct=False)
+    ab = line["config"]["rccl"]["comm_priority_ab"]
+    assert set(ab["ms_per_step"]) == {"normal", "high"} and all(v > 0 for v in ab["ms_per_step"].values())
+    assert ab["kept"] == line["config"]["rccl"]["comm_priority"] and ab["kept"] in ("normal", "high")
+    if ab["kept"] == "high":
+        assert ab["ms_per_step"]["high"] < 0.98 * ab["ms_per_step"]["normal"]
+
+
 def _nccl_fake_host_worker(rank, world, port, n, steps, comm, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
