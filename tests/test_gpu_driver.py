@@ -152,6 +152,39 @@ def test_headless_local_transport_at_the_block_sizes_a_node_runs(nb, tmp_path):
     assert r.returncode != 0 and "--transport local" in r.stderr
 
 
+def test_in_place_step_with_the_gpu_shared_between_processes(tmp_path):
+    """What the in-place fused step's protocol is for: it never waits for a workgroup that has not started, so nothing deadlocks when
+    the 256 workgroups of a launch are NOT all resident — here three processes step the reference's loop (one synchronous simulate()
+    per step, N = 8192: one workgroup per CU each) on the one GPU at the same time, and a fourth keeps it busy with queued steps of a
+    large system. Every run must finish, and every result must be bit-identical to the same run with the GPU to itself — whether a
+    wave wrote in place or through the spare array (`inplace_fallback_waves` says how many did)."""
+    n, steps = 8192, 1500
+    base = [DRIVER, "--n", str(n), "--steps", str(steps), "--init", "libc", "--sync-each-step"]
+    alone = json.loads(_run([*base, "--dump", str(tmp_path / "alone")]).strip().splitlines()[-1])
+    assert alone["steps"] == steps and alone["inplace_fallback_waves"] >= 0
+    hog = subprocess.Popen([DRIVER, "--n", "131072", "--steps", "1500", "--init", "plummer", "--dt", "0.01", "--quiet"],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    procs = [subprocess.Popen([*base, "--dump", str(tmp_path / f"shared{k}")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for k in range(3)]
+    outs = []
+    try:
+        for p in procs:
+            out, err = p.communicate(timeout=240)
+            assert p.returncode == 0, err
+            outs.append(json.loads(out.strip().splitlines()[-1]))
+        hog.communicate(timeout=240)
+        assert hog.returncode == 0
+    finally:
+        for p in procs + [hog]:
+            if p.poll() is None:
+                p.kill()
+    for k in range(3):
+        for ext in ("x", "v", "a"):
+            assert np.array_equal(_f4(tmp_path / f"alone.{ext}.f4", n), _f4(tmp_path / f"shared{k}.{ext}.f4", n)), (k, ext)
+    print("in-place fall-back waves: alone", alone["inplace_fallback_waves"], "shared", [o["inplace_fallback_waves"] for o in outs],
+          "us/step alone %.1f shared %s" % (alone["seconds"] / steps * 1e6, ["%.1f" % (o["seconds"] / steps * 1e6) for o in outs]))
+
+
 def test_compare_host_to_device_program():
     """compareHostToDevice in the reference's own terms: lock-step GPU/CPU steps, then the 1 % rule on
     positions, velocities and accelerations."""
