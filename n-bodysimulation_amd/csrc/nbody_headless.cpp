@@ -147,6 +147,7 @@ int main(int argc, char** argv)
                         : kernel == NBODY_KERNEL_SYMMETRIC ? "symmetric" : "fast";
     double secs = 0.0;
     unsigned long long inplace_fallback_waves = 0;
+    int autotuned_choice = -1;
     if (ngpu > 1 || force_shard) {
         // G ranks in this process: one thread, one device, one context, one RCCL communicator and one shard each
         int ndev = 0;
@@ -344,6 +345,7 @@ int main(int argc, char** argv)
     }
     secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::printf("Simulation complete\n");                // main.cpp:158
+    if (sync_each) ok(nbody_ctx_autotuned(ctx, n, &autotuned_choice, nullptr, nullptr));   // what simulate()'s one-off measurement decided for this size (-1: none)
     if (sync_each) ok(nbody_ctx_fused_inplace_stats(ctx, &inplace_fallback_waves));   // waves of the in-place step that wrote to the spare array (0 when the GPU was ours alone)
 
     ok(nbody_memcpy_d2h(bodies, d_bodies, bytes));
@@ -366,9 +368,9 @@ int main(int argc, char** argv)
     if (json) {
         const double pairs = (double)n * (double)n * steps;
         std::printf("{\"n\": %d, \"steps\": %d, \"dt\": %.9g, \"eps2\": %.9g, \"kernel\": \"%s\", \"ngpu\": %d, \"seconds\": %.6f, \"pairs_per_s\": %.6g, "
-                    "\"gflops_at_20\": %.6g, \"inplace_fallback_waves\": %llu, \"body0\": [%.9g, %.9g, %.9g, %.9g]}\n",
+                    "\"gflops_at_20\": %.6g, \"inplace_fallback_waves\": %llu, \"autotuned_choice\": %d, \"body0\": [%.9g, %.9g, %.9g, %.9g]}\n",
                     n, steps, dt, eps2, kname, ngpu, secs, secs > 0 ? pairs / secs : 0.0,
-                    secs > 0 ? 20.0 * pairs / secs / 1e9 : 0.0, inplace_fallback_waves, n ? bodies[0].x : 0.f, n ? bodies[0].y : 0.f, n ? bodies[0].z : 0.f,
+                    secs > 0 ? 20.0 * pairs / secs / 1e9 : 0.0, inplace_fallback_waves, autotuned_choice, n ? bodies[0].x : 0.f, n ? bodies[0].y : 0.f, n ? bodies[0].z : 0.f,
                     n ? bodies[0].w : 0.f);
     }
     ok(nbody_free_host(bodies));
