@@ -225,6 +225,12 @@ int nbody_ctx_autotuned(nbody_ctx* ctx, int n, int* out_choice, double* out_us_b
 /* Pins what nbody_simulate() uses for n bodies instead of measuring (a caller that wants the same decomposition, hence the same
  * low-order bits, on every machine): choice 0 = built-in, an id of nbody_ctx_autotune = that decomposition, -1 = forget n. */
 int nbody_ctx_set_autotuned(nbody_ctx* ctx, int n, int choice);
+/* The decision rule itself (pure host logic, no device): may a measured challenger override the built-in decomposition? 1 = yes.
+ * The built-in choice timed first and last must agree with itself within 10 % (a quiet machine), the challenger must beat it by
+ * more than `margin` (0.03), and — when n_confirm > 0 — every confirmation trial of the challenger must beat every confirmation
+ * trial of the built-in choice by that margin. */
+int nbody_autotune_decide(double builtin_first_us, double builtin_last_us, double challenger_us, const double* confirm_builtin_us,
+                          const double* confirm_challenger_us, int n_confirm, double margin);
 
 /* Pre-size the slab workspace for up to n_targets bodies so later calls never allocate. */
 int nbody_ctx_reserve(nbody_ctx* ctx, int n_targets);

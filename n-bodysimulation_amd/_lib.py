@@ -82,6 +82,7 @@ _SIGNATURES = {
     "nbody_ctx_set_symmetric_runs": (C.c_int, [_p, C.c_int]),
     "nbody_ctx_autotune": (C.c_int, [_p, _p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "nbody_ctx_set_autotuned": (C.c_int, [_p, C.c_int, C.c_int]),
+    "nbody_autotune_decide": (C.c_int, [C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_double]),
     "nbody_ctx_autotuned": (C.c_int, [_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "nbody_ctx_set_fused": (C.c_int, [_p, C.c_int]),
     "nbody_ctx_set_fused_inplace": (C.c_int, [_p, C.c_int]),

@@ -1855,6 +1855,31 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
     return NBODY_OK;
 }
 
+// The rule by which a timing measurement may override the built-in decomposition (pure host logic: tests/test_abi.py). 1 = override.
+//  (a) the built-in choice, timed first and last, agrees with itself within 10 % (else the machine is not quiet);
+//  (b) the challenger's best time beats the built-in's best by more than `margin`;
+//  (c) when confirmation trials are given: EVERY challenger trial beats EVERY built-in trial by more than `margin`.
+extern "C" int nbody_autotune_decide(double builtin_first_us, double builtin_last_us, double challenger_us, const double* confirm_builtin_us,
+                                     const double* confirm_challenger_us, int n_confirm, double margin)
+{
+    if (!(builtin_first_us > 0.0) || !(builtin_last_us > 0.0) || !(challenger_us > 0.0) || !(margin > 0.0) || n_confirm < 0) return 0;
+    const double lo = builtin_first_us < builtin_last_us ? builtin_first_us : builtin_last_us;
+    const double hi = builtin_first_us < builtin_last_us ? builtin_last_us : builtin_first_us;
+    if (hi > 1.10 * lo) return 0;
+    if (!(challenger_us < lo * (1.0 - margin))) return 0;
+    if (n_confirm > 0) {
+        if (!confirm_builtin_us || !confirm_challenger_us) return 0;
+        double ch_max = 0.0, bi_min = 1e300;
+        for (int k = 0; k < n_confirm; ++k) {
+            if (!(confirm_builtin_us[k] > 0.0) || !(confirm_challenger_us[k] > 0.0)) return 0;
+            if (confirm_builtin_us[k] < bi_min) bi_min = confirm_builtin_us[k];
+            if (confirm_challenger_us[k] > ch_max) ch_max = confirm_challenger_us[k];
+        }
+        if (!(ch_max < bi_min * (1.0 - margin))) return 0;
+    }
+    return 1;
+}
+
 namespace {
 
 struct TuneKnobs { int fused, sym_runs, sym_bpl, sym_waves; };
@@ -1941,21 +1966,17 @@ int tune_measure(nbody_ctx* c, const nbody_float4* d_bodies, int n, int steps_pe
         //  (a) the built-in choice, timed first and last, must agree with itself within 10 % (else the machine is not quiet: keep it);
         //  (b) the challenger must be faster by more than the margin;
         //  (c) and again in a confirmation round: three alternating trials each, EVERY challenger trial faster than EVERY built-in trial by the margin.
-        bool override_it = best > 0 && best_us < builtin_us * (1.0 - keep_builtin_within);
-        const double lo = builtin_first < builtin_last ? builtin_first : builtin_last, hi = builtin_first < builtin_last ? builtin_last : builtin_first;
-        if (override_it && hi > 1.10 * lo) override_it = false;
+        bool override_it = best > 0 && nbody_autotune_decide(builtin_first, builtin_last, best_us, nullptr, nullptr, 0, keep_builtin_within) == 1;
         if (override_it) {
-            double ch_max = 0.0, bi_min = 1e30;
+            double tb[3] = {0, 0, 0}, tc[3] = {0, 0, 0};
             for (int round = 0; round < 3 && override_it; ++round) {
                 c->fused = saved.fused; c->sym_runs = saved.sym_runs; c->sym_bpl = saved.sym_bpl; c->sym_waves = saved.sym_waves;
-                const double tb = one_trial();
+                tb[round] = one_trial();
                 c->fused = best_k.fused; c->sym_runs = best_k.sym_runs; c->sym_bpl = best_k.sym_bpl; c->sym_waves = best_k.sym_waves;
-                const double tc = one_trial();
-                if (tb < 0.0 || tc < 0.0) { override_it = false; break; }
-                if (tb < bi_min) bi_min = tb;
-                if (tc > ch_max) ch_max = tc;
+                tc[round] = one_trial();
+                if (tb[round] < 0.0 || tc[round] < 0.0) override_it = false;
             }
-            if (override_it && !(ch_max < bi_min * (1.0 - keep_builtin_within))) override_it = false;
+            if (override_it) override_it = nbody_autotune_decide(builtin_first, builtin_last, best_us, tb, tc, 3, keep_builtin_within) == 1;
         }
         if (!override_it) { best = 0; best_us = builtin_us; best_k = saved; }
     }

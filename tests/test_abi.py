@@ -214,3 +214,20 @@ def test_local_group_and_pin_arguments_without_a_device(nb):
     assert lib.nbody_comm_local_create(C.byref(comm), g, 3, 0) == L.ERR_INVALID      # rank 3 of 3
     assert lib.nbody_comm_local_destroy(C.byref(comm)) == L.OK                         # never created: nothing to do
     assert lib.nbody_comm_local_group_destroy(g) == L.OK and lib.nbody_comm_local_group_destroy(None) == L.OK
+
+
+def test_autotune_decision_rule(nb):
+    """nbody_autotune_decide: a measurement may override the built-in decomposition only by a clear and repeatable win on a quiet
+    machine — the choice decides the low-order bits of every later result (a busy GPU flipped one run in six under the first rule)."""
+    lib = nb.load()
+    arr = lambda *v: (C.c_double * len(v))(*v)
+    decide = lambda bf, bl, ch, cb=None, cc=None, m=0.03: lib.nbody_autotune_decide(bf, bl, ch, cb, cc, len(cb) if cb is not None else 0, m)
+    assert decide(20.0, 20.2, 19.0) == 1                                   # quiet, 5 % faster
+    assert decide(20.0, 20.2, 19.5) == 0                                   # 2.5 %: inside the margin
+    assert decide(20.0, 23.0, 15.0) == 0                                   # the built-in choice disagrees with itself by 15 %: not quiet
+    assert decide(23.0, 20.0, 15.0) == 0
+    assert decide(20.0, 20.0, 19.0, arr(20.1, 20.0, 20.3), arr(19.0, 19.1, 18.9)) == 1
+    assert decide(20.0, 20.0, 19.0, arr(20.1, 20.0, 20.3), arr(19.0, 19.6, 18.9)) == 0    # one confirmation trial too slow
+    assert decide(20.0, 20.0, 19.0, arr(20.1, 19.2, 20.3), arr(19.0, 19.1, 18.9)) == 0    # one built-in trial as fast as the challenger
+    assert decide(20.0, 20.0, 19.0, arr(20.1, -1.0, 20.3), arr(19.0, 19.1, 18.9)) == 0    # a failed trial
+    assert decide(0.0, 20.0, 19.0) == 0 and decide(20.0, 20.0, 0.0) == 0 and decide(20.0, 20.0, 19.0, m=0.0) == 0
