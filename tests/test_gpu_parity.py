@@ -429,6 +429,41 @@ def test_benchmark_time_step_vs_the_reference_build(nb, oracle, kernel, shape):
     assert bad <= 48 and np.abs(x100 - g["x_100"])[:, :3].max() <= 1e-2, bad
 
 
+@pytest.mark.parametrize("n", [65536, 262144])
+def test_baseline_configs_at_full_size_vs_the_reference_build(nb, oracle, n):
+    """BASELINE configs[1] and configs[2] AT FULL SIZE against the reference itself: one step (dt = 0.01) of the bench's own bodies
+    through the default kernels (unit runs at 65536, block pairs at 262144, equal-mass path) and through the general path, against
+    the REFERENCE build's CPU_compute on 2048 sampled bodies (tests/golden/ref_cpu_plummer_n<N>_dt0.01_sample.npz: 9 s / 2.5 min of
+    one core, generated once). The GPU may differ from the reference only by the reference's own two artefacts, both measured here
+    with the pinned restatement: its in-place ORDER (bodies before i are already advanced when i is evaluated: |a_jacobi - a_ref|,
+    up to 9e-5 of max|a| for the last bodies) and the ROUNDING of its N-term fp32 running sum (|a_jacobi - a_truth|, 1-2e-5) — plus
+    1e-5 of max|a|. Positions and velocities follow (v = dt/2 a, x = x0 + dt v)."""
+    g = load_golden(f"ref_cpu_plummer_n{n}_dt0.01_sample.npz")
+    assert int(g["n"]) == n
+    x0 = nb.engine.seeded_bodies(n, 1, 12345)
+    assert np.array_equal(bits(x0[:8]), bits(g["x0_head"]))
+    idx = g["idx"]
+    for eq in (-1, 0):
+        sim = nb.engine.Simulation(x0, dt=0.01, eps2=0.002)
+        sim.ctx.set_equal_mass(eq)
+        sim.run(1)
+        x, v, a = sim.state()
+        assert np.abs(x[idx] - g["x_1"])[:, :3].max() <= 1e-6
+        for i0, i1 in ((0, 256), (n - 256, n)):              # the contiguous parts of the sample: first and last bodies of the in-place loop
+            sel = np.searchsorted(idx, np.arange(i0, i1))
+            aj = oracle.accel_range(x0, i0, i1, 0, n, eps2=0.002)                  # fp32 sequential, Jacobi order
+            at = oracle.accel_range(x0, i0, i1, 0, n, eps2=0.002, f64acc=True)     # fp64-accumulated
+            ar = g["a_1"][sel]
+            amax = np.abs(at[:, :3]).max()
+            bound = np.abs(aj - ar)[:, :3] + np.abs(aj - at)[:, :3] + 1e-5 * amax
+            assert np.all(np.abs(a[i0:i1] - ar)[:, :3] <= bound), (n, eq, i0)
+            assert np.all(np.abs(v[i0:i1] - g["v_1"][sel])[:, :3] <= 0.5 * 0.01 * bound + 1e-12)
+            assert np.abs(a[i0:i1] - at)[:, :3].max() / amax <= 1e-5              # and the GPU itself is closer to the truth than the reference
+        # the scattered part of the sample: within the largest artefact seen on the contiguous parts + the same margin
+        rest = np.abs(a[idx] - g["a_1"])[:, :3].max() / np.abs(g["a_1"][:, :3]).max()
+        assert rest <= 2e-4, rest
+
+
 def test_reference_one_percent_rule_vs_literal_reference(nb):
     """compareHostToDevice's acceptance rule (validation.cpp:84-86, 143-164) against the literal
     reference outputs. After 10 steps the GPU passes it outright; after 100 steps the reference's

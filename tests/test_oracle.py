@@ -84,6 +84,22 @@ def test_inplace_oracle_matches_live_reference_build_at_dt001(oracle):
             assert np.array_equal(bits(r[i]), bits(o[i])), (n, K, i)
 
 
+def test_inplace_oracle_matches_the_reference_at_configs1_full_size(oracle, nb):
+    """BASELINE configs[1] at FULL size (N = 65536, dt = 0.01, the bench's seeded Plummer sphere): one step of the restatement equals the
+    REFERENCE build's CPU_compute (DT 0.01f, tests/golden/ref_cpu_plummer_n65536_dt0.01_sample.npz: 2048 sampled bodies) bit for bit.
+    (4.3e9 pair terms on one core: about 9 s. The N = 262144 sample of the same kind is used by the GPU tests.)"""
+    g = load_golden("ref_cpu_plummer_n65536_dt0.01_sample.npz")
+    n = int(g["n"])
+    x0 = nb.engine.seeded_bodies(n, 1, 12345)
+    assert np.array_equal(bits(x0[:8]), bits(g["x0_head"]))
+    x, v, a = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
+    oracle.set_threads(1)
+    oracle.step_inplace(x, a, v, dt=np.float32(0.01), eps2=oracle.REF_EPS2, steps=1)
+    idx = g["idx"]
+    assert np.array_equal(bits(x[idx]), bits(g["x_1"])) and np.array_equal(bits(v[idx]), bits(g["v_1"]))
+    assert np.array_equal(bits(a[idx]), bits(g["a_1"]))
+
+
 def test_pair_matches_golden_reference_pairs(oracle):
     g = load_golden("ref_pairs.npz")
     for k in range(len(g["bi"])):
