@@ -429,12 +429,12 @@ def test_benchmark_time_step_vs_the_reference_build(nb, oracle, kernel, shape):
     assert bad <= 48 and np.abs(x100 - g["x_100"])[:, :3].max() <= 1e-2, bad
 
 
-@pytest.mark.parametrize("n", [65536, 262144])
+@pytest.mark.parametrize("n", [65536, 262144, 1048576])
 def test_baseline_configs_at_full_size_vs_the_reference_build(nb, oracle, n):
-    """BASELINE configs[1] and configs[2] AT FULL SIZE against the reference itself: one step (dt = 0.01) of the bench's own bodies
+    """BASELINE configs[1], configs[2] and the system of configs[3] (N = 1048576, here on one GPU) AT FULL SIZE against the reference itself: one step (dt = 0.01) of the bench's own bodies
     through the default kernels (unit runs at 65536, block pairs at 262144, equal-mass path) and through the general path, against
-    the REFERENCE build's CPU_compute on 2048 sampled bodies (tests/golden/ref_cpu_plummer_n<N>_dt0.01_sample.npz: 9 s / 2.5 min of
-    one core, generated once). The GPU may differ from the reference only by the reference's own two artefacts, both measured here
+    the REFERENCE build's CPU_compute on 2048 sampled bodies (tests/golden/ref_cpu_plummer_n<N>_dt0.01_sample.npz: 9 s / 2.5 min / 50 min
+    of one core, generated once). The GPU may differ from the reference only by the reference's own two artefacts, both measured here
     with the pinned restatement: its in-place ORDER (bodies before i are already advanced when i is evaluated: |a_jacobi - a_ref|,
     up to 9e-5 of max|a| for the last bodies) and the ROUNDING of its N-term fp32 running sum (|a_jacobi - a_truth|, 1-2e-5) — plus
     1e-5 of max|a|. Positions and velocities follow (v = dt/2 a, x = x0 + dt v)."""
@@ -461,7 +461,7 @@ def test_baseline_configs_at_full_size_vs_the_reference_build(nb, oracle, n):
             assert np.abs(a[i0:i1] - at)[:, :3].max() / amax <= 1e-5              # and the GPU itself is closer to the truth than the reference
         # the scattered part of the sample: within the largest artefact seen on the contiguous parts + the same margin
         rest = np.abs(a[idx] - g["a_1"])[:, :3].max() / np.abs(g["a_1"][:, :3]).max()
-        assert rest <= 2e-4, rest
+        assert rest <= (2e-4 if n <= 262144 else 5e-4), rest
 
 
 def test_reference_one_percent_rule_vs_literal_reference(nb):
