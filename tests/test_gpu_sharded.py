@@ -165,6 +165,40 @@ def test_callback_ranks_symmetric_at_block_sizes_the_bench_uses(nb, oracle):
     assert np.array_equal(a, a2) and np.array_equal(x, x2) and np.array_equal(v, v2)
 
 
+def test_configs3_decomposition_vs_the_reference_build(nb, oracle):
+    """BASELINE configs[3] as the driver runs it — N = 1048576 bodies in EIGHT blocks of 131072, symmetric schedule (own-block halves,
+    3 1/2 cross launches per rank, J-side sums exchanged, fixed-order adds), dt = 0.01 — one step through the native sharded step with
+    eight callback ranks on this one device, against the REFERENCE build's CPU_compute (DT 0.01f) on 2048 sampled bodies
+    (tests/golden/ref_cpu_plummer_n1048576_dt0.01_sample.npz: 78 minutes of one core, generated once). Same bar as the single-GPU test
+    of that fixture: the difference stays within the reference's own in-place order and fp32 running-sum rounding, both measured here
+    with the pinned restatement, + 1e-5 of max|a|; and the eight-rank result agrees with the single-GPU kernel to 2e-6 of max|a|."""
+    from conftest import bits, load_golden
+    g = load_golden("ref_cpu_plummer_n1048576_dt0.01_sample.npz")
+    n, world = int(g["n"]), 8
+    x0 = nb.engine.seeded_bodies(n, 1, 12345)
+    assert np.array_equal(bits(x0[:8]), bits(g["x0_head"]))
+    ranks = _OneThreadRanks(nb, x0, world, nb.KERNEL_FAST, 0.01, 0.002)
+    assert ranks.plans[0].schedule == 2 and ranks.plans[0].shard == n // world
+    ranks.step(1)
+    x, v, a = ranks.state(n)
+    ranks.close()
+    idx = g["idx"]
+    assert np.abs(x[idx] - g["x_1"])[:, :3].max() <= 1e-6
+    for i0, i1 in ((0, 256), (n - 256, n)):
+        sel = np.searchsorted(idx, np.arange(i0, i1))
+        aj = oracle.accel_range(x0, i0, i1, 0, n, eps2=0.002)
+        at = oracle.accel_range(x0, i0, i1, 0, n, eps2=0.002, f64acc=True)
+        ar = g["a_1"][sel]
+        amax = np.abs(at[:, :3]).max()
+        bound = np.abs(aj - ar)[:, :3] + np.abs(aj - at)[:, :3] + 1e-5 * amax
+        assert np.all(np.abs(a[i0:i1] - ar)[:, :3] <= bound), i0
+        assert np.abs(a[i0:i1] - at)[:, :3].max() / amax <= 1e-5
+    one = nb.engine.Simulation(x0, dt=0.01, eps2=0.002)
+    one.run(1)
+    a1 = one.state()[2]
+    assert np.abs(a[idx] - a1[idx])[:, :3].max() / np.abs(a1[:, :3]).max() <= 2e-6
+
+
 def test_native_rccl_comm_with_one_rank(nb):
     """nbody_comm_rccl_* (librccl loaded at run time, ncclCommInitRank / ncclAllGather / grouped send-recv) through
     the C entry points, as far as a 1-GPU box allows: a world of one, bit-equal to nbody_step."""
