@@ -159,8 +159,10 @@ int nbody_ctx_set_fused(nbody_ctx* ctx, int mode);
  * per call, the reference's loop (main.cpp:146-156) — runs its step in place and waits on a host-mapped word the launch writes
  * when all its results are in memory, instead of a copy-back launch and a stream synchronisation (N = 8192: 30 us per call
  * against 33.5); queued steps keep the two-array kernel, which is faster when nobody waits (20.3 against 23.6 us per step).
- * 0: never (two arrays + copy-back, the round-3 behaviour); 1: every fused step; 2: as 1 with every wave forced down the
- * fall-back path (tests). */
+ * Above 8192 bodies (other kernels) nbody_simulate() queues one tiny launch that writes the same word behind the step and waits
+ * on it likewise (about 4 us per call less than a stream synchronisation).
+ * 0: never (two arrays + copy-back and a plain stream synchronisation, the round-3 behaviour); 1: every fused step; 2: as 1 with
+ * every wave forced down the fall-back path (tests). */
 int nbody_ctx_set_fused_inplace(nbody_ctx* ctx, int mode);
 /* Waves that took the fall-back path of the in-place step since the context was created (synchronises the stream). */
 int nbody_ctx_fused_inplace_stats(nbody_ctx* ctx, unsigned long long* out_fallback_waves);

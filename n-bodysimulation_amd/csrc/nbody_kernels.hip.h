@@ -1466,6 +1466,14 @@ __global__ void __launch_bounds__(256) copy_bodies(float4* __restrict__ dst, con
     if (i < n) dst[i] = src[i];
 }
 
+// One 64-bit word to host-mapped memory: launched behind the last kernel of a synchronous call (nbody_simulate on the paths that are
+// not the fused step), so that the host can wait on the word instead of a stream synchronisation. The launch boundary in front of it is
+// what makes the step's results visible first: the runtime's release between two kernels of one stream writes the L2s back.
+__global__ void __launch_bounds__(64) host_signal(unsigned long long* host_word, unsigned long long value)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(host_word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // INPLACE = true: the same step with the advanced positions written back INTO the array they were read from — one launch, no spare
 // array to alternate with, no copy-back launch after an odd number of steps (what a caller who steps once per synchronous call, like
 // the reference's loop main.cpp:146-156, pays every call). In place is only safe once EVERY workgroup has read everything it will
