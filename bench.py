@@ -4,6 +4,8 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--bodies B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+Both forms work for N > 1: started without the launcher, `bench.py --gpus N` starts that launcher line itself as a child process
+(one rank per GPU, rendezvous on 127.0.0.1 and a free port), relays its output and ends with its exit code.
 
 A "step" is one pass of the hot path over all bodies: the O(N^2) force accumulation followed by
 the half-kick/drift integrate (TestProject/kernel.cu:80-130 in the reference).
@@ -148,6 +150,33 @@ def ensure_built() -> None:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
+def rank_launch_command(gpus: int, argv, port: int):
+    """What `python bench.py --gpus G ...` runs when nobody wrapped it in the launcher: the driver's own form, one rank per GPU."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def spawn_ranks(gpus: int) -> int:
+    """Starts the ranks as a CHILD process (never an exec: this process may not be replaced once a GPU runtime is loaded, and a child
+    keeps the exit code honest), lets them write to this process's stdout / stderr, forwards SIGTERM / SIGINT, returns their exit code."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL between processes needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")              # what the launcher would set itself, with a warning
+    proc = subprocess.Popen(rank_launch_command(gpus, sys.argv[1:], port), env=env)
+    def forward(signum, _frame):
+        if proc.poll() is None:
+            proc.send_signal(signum)
+    for sg in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sg, forward)
+    return proc.wait()
+
+
 def cpu_baseline(seconds_budget: float = 12.0):
     """Times the reference's CPU step (serial, as the reference builds it) on a bounded sample."""
     import numpy as np
@@ -244,11 +273,14 @@ def main():
     ap.add_argument("--masses", default="init", choices=["init", "random"], help="init: as the initial conditions give them (Plummer: every body 1/N, "
                     "which the symmetric kernels' equal-mass path picks up; cube: the reference's random masses); random: Plummer positions "
                     "with masses drawn uniformly over a decade, as the reference's fill_with_random4 does, total 1 - the general path")
-    ap.add_argument("--equal-mass", default="auto", choices=["auto", "on", "off"], help="auto: the library's default (launches of 32768 bodies "
-                    "or more are scanned for one common mass); on: from 4096 bodies; off: nbody_ctx_set_equal_mass(0), the general pair "
-                    "arithmetic whatever the masses")
-    ap.add_argument("--no-general-path", action="store_true", help="skip the extra repeats that time the general pair arithmetic when the "
-                    "timed steps took the equal-mass path (profile runs: only the timed kernels in the trace)")
+    ap.add_argument("--equal-mass", default="headline", choices=["headline", "auto", "on", "off"], help="which pair arithmetic the TIMED steps run. "
+                    "headline (default): the GENERAL arithmetic (nbody_ctx_set_equal_mass(0): what unequal masses, e.g. the reference's own "
+                    "fill_with_random4 bodies, get) - value / ms_per_step / roofline.frac do not depend on the input's masses; when the bodies do "
+                    "all carry one mass, three extra repeats with the library's default switched back on are reported beside it "
+                    "(equal_mass_value, roofline.frac_equal_mass). auto: the library's default for the timed steps (launches of 32768 bodies or "
+                    "more are scanned for one common mass); on: from 4096 bodies; off: general arithmetic, no extras")
+    ap.add_argument("--no-equal-mass-extras", "--no-general-path", dest="no_extras", action="store_true", help="skip the three extra repeats on the "
+                    "equal-mass path (profile runs: only the timed kernels in the trace)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="f64 = the build's own double-precision variant "
                     "(BASELINE configs[4]; single GPU only)")
@@ -272,6 +304,12 @@ def main():
     args = ap.parse_args()
     arm_stall_dump()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus G` started directly: this process becomes the launcher of its own G ranks (before torch is imported
+        # and before anything touches a GPU) and ends with their exit code
+        ensure_built()
+        raise SystemExit(spawn_ranks(args.gpus))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -287,10 +325,7 @@ def main():
     import torch.distributed as dist
     import nbody_amd
 
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("for --gpus > 1 launch through torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world   # (under the launcher the environment decides; `--gpus G` without it has started its own ranks above)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     ndev = torch.cuda.device_count()
@@ -376,7 +411,7 @@ def main():
             s1 = nbody_amd.engine.Simulation(x0, dt=args.dt, eps2=args.eps2, device=dev.index, **kopts)
             if args.sym_waves or args.sym_bpl:
                 s1.ctx.set_symmetric_shape(args.sym_waves, args.sym_bpl)
-            s1.ctx.set_equal_mass({"auto": -1, "on": 1, "off": 0}[args.equal_mass])
+            s1.ctx.set_equal_mass({"headline": 0, "auto": -1, "on": 1, "off": 0}[args.equal_mass])
             k1 = max(1, min(args.steps, int(math.ceil(2.0 / (float(n) * n / 6.5e12)))))   # about 2 s of steps, at most --steps
             s1.run(1, sync=False)
             s1.ctx.sync()
@@ -442,7 +477,7 @@ def main():
         info["schedule"] = {0: "canonical", 1: "onesided", 2: "symmetric"}[plan.schedule]
         info["cross_launches"] = [[plan.launch[l].i0, plan.launch[l].i1, plan.launch[l].j0, plan.launch[l].count] for l in range(plan.n_launches)]
 
-    eq_mode = {"auto": -1, "on": 1, "off": 0}[args.equal_mass]
+    eq_mode = {"headline": 0, "auto": -1, "on": 1, "off": 0}[args.equal_mass]
     ctx.set_equal_mass(eq_mode)
     steps_done = [0]          # every step this process asks for (the fp64 line compares with an fp32 run of the same length)
     _run_steps = run
@@ -588,42 +623,50 @@ def main():
             rccl["comm_priority_ab"] = priority_ab
 
     # Equal masses (a Plummer sphere: every body 1/N) let the symmetric kernels factor the common mass out of the pair sums; the
-    # decision is taken on the device per launch. Say whether the timed steps took that path, and time the GENERAL path (what a
-    # system with unequal masses, e.g. the reference's own initial conditions, gets) on the same bodies right here.
+    # decision is taken on the device per launch. The TIMED steps above ran the general arithmetic (--equal-mass headline / off) unless
+    # the caller asked for the library's default; say which, and — headline mode — time the library's default on the same bodies right
+    # here, as an extra: it is what THIS input gets from the library, but not a figure an input with unequal masses can reach.
     v = ctx.equal_mass_verdict()
-    equal_mass = {"path_taken": bool(v["scanned"] and v["uniform"]), "decided": "on the device, per launch (nbk::mass_scan); nbody_ctx_set_equal_mass(0) or --equal-mass off disables it",
-                  "masses": ("all equal: %.9g" % v["mass"]) if v["scanned"] and v["uniform"] else "not all equal (or never scanned): general pair arithmetic"}
-    # (a collective decision: every rank times the general path or none does)
-    equal_mass["path_taken_on_every_rank"] = max_over_ranks(0.0 if equal_mass["path_taken"] else 1.0) == 0.0
-    if equal_mass["path_taken_on_every_rank"] and not args.no_general_path:
-        phase("general_path")
-        ctx.set_equal_mass(0)
+    took = bool(eq_mode != 0 and v["scanned"] and v["uniform"])
+    equal_mass = {"path_taken": took, "timed_steps_ran": "equal-mass path" if took else "general pair arithmetic",
+                  "decided": ("--equal-mass %s: the timed steps ran with nbody_ctx_set_equal_mass(0), the general arithmetic whatever the masses" % args.equal_mass) if eq_mode == 0 else
+                             "on the device, per launch (nbk::mass_scan); nbody_ctx_set_equal_mass(0) disables it"}
+    equal_mass["path_taken_on_every_rank"] = max_over_ranks(0.0 if took else 1.0) == 0.0
+    if args.equal_mass == "headline" and not args.no_extras:
+        phase("equal_mass_extras")
+        ctx.set_equal_mass(-1)   # the library's default
         run(2)
-        gen, gen_kernel_ms = [], []
-        if inline_events:
-            ctx.timing(True)
-            barrier()
-            ctx.timing_read()
-        for _ in range(3):
-            barrier()
-            t0 = time.perf_counter()
-            run(args.steps)
-            barrier()
-            gen.append(max_over_ranks(time.perf_counter() - t0))
-            gen_kernel_ms.append(ctx.timing_read()[0] if inline_events else 0.0)
-        ctx.timing(False)
+        barrier()
+        v = ctx.equal_mass_verdict()
+        # (a collective decision: every rank times the extras or none does)
+        on_all = max_over_ranks(0.0 if (v["scanned"] and v["uniform"]) else 1.0) == 0.0
+        equal_mass["masses"] = ("all equal: %.9g" % v["mass"]) if v["scanned"] and v["uniform"] else "not all equal (or below the size the library scans from): general pair arithmetic is all there is"
+        if on_all:
+            eqt, eq_kernel_ms = [], []
+            if inline_events:
+                ctx.timing(True)
+                barrier()
+                ctx.timing_read()
+            for _ in range(3):
+                barrier()
+                t0 = time.perf_counter()
+                run(args.steps)
+                barrier()
+                eqt.append(max_over_ranks(time.perf_counter() - t0))
+                eq_kernel_ms.append(ctx.timing_read()[0] if inline_events else 0.0)
+            ctx.timing(False)
+            g = statistics.median(eqt)
+            # force-kernel seconds per step by HIP events (this rank); small systems run un-instrumented: the whole step stands in
+            gk = statistics.median(eq_kernel_ms) * 1e-3 / args.steps if inline_events else g / args.steps
+            pk = FP64_VECTOR_PEAK_TFLOPS if f64 else FP32_VECTOR_PEAK_TFLOPS
+            rp = float(sim.shard) * sim.n_pad if multi else float(n) * n
+            equal_mass["equal_mass_path"] = {"ms_per_step": g / args.steps * 1e3, "value": float(n) * n * args.steps / g, "unit": "pairs/s",
+                                             "kernel_ms_per_step": gk * 1e3,
+                                             "frac_of_peak_at_20_flop": FLOP_PER_PAIR * rp / gk / 1e12 / pk if gk > 0 else None,
+                                             "frac_source": "force kernel's HIP-event time, as roofline.frac" if inline_events else "whole-step wall time (no per-launch events at this size)",
+                                             "repeats": 3, "note": "same bodies, same run, the library's default (equal-mass path where the device-side scan finds one common "
+                                                                   "mass): 14 instead of 16 packed ops per two pair evaluations; an input-dependent figure, not the headline"}
         ctx.set_equal_mass(eq_mode)
-        g = statistics.median(gen)
-        # force-kernel seconds per step by HIP events (this rank); small systems run un-instrumented: the whole step stands in
-        gk = statistics.median(gen_kernel_ms) * 1e-3 / args.steps if inline_events else g / args.steps
-        pk = FP64_VECTOR_PEAK_TFLOPS if f64 else FP32_VECTOR_PEAK_TFLOPS
-        rp = float(sim.shard) * sim.n_pad if multi else float(n) * n
-        equal_mass["general_path"] = {"ms_per_step": g / args.steps * 1e3, "value": float(n) * n * args.steps / g, "unit": "pairs/s",
-                                      "kernel_ms_per_step": gk * 1e3,
-                                      "frac_of_peak_at_20_flop": FLOP_PER_PAIR * rp / gk / 1e12 / pk if gk > 0 else None,
-                                      "frac_source": "force kernel's HIP-event time, as roofline.frac" if inline_events else "whole-step wall time (no per-launch events at this size)",
-                                      "frac_of_peak_whole_step": FLOP_PER_PAIR * float(n) * n * args.steps / g / 1e12 / (pk * world),
-                                      "repeats": 3, "note": "same bodies, same run, equal-mass path switched off: what unequal masses get"}
 
     elapsed = statistics.median(repeats)
     pairs_step = float(n) * n
@@ -679,10 +722,11 @@ def main():
         "ms_per_step_min": min(repeats) / args.steps * 1e3,
         "ms_per_step_max": max(repeats) / args.steps * 1e3,
         "per_gpu_value": value / world,
-        # which pair arithmetic the timed steps ran (decided on the device from the masses), and the other one beside it
-        **({"equal_mass_path": equal_mass["path_taken"]} if equal_mass else {}),
-        **({"general_path_value": equal_mass["general_path"]["value"], "general_path_ms_per_step": equal_mass["general_path"]["ms_per_step"]}
-           if equal_mass and equal_mass.get("general_path") else {}),
+        # which pair arithmetic the timed steps ran (false by default: the general one, whatever the masses), and the library's default
+        # on THIS input beside it
+        "equal_mass_path": equal_mass["path_taken"],
+        **({"equal_mass_value": equal_mass["equal_mass_path"]["value"], "equal_mass_ms_per_step": equal_mass["equal_mass_path"]["ms_per_step"]}
+           if equal_mass.get("equal_mass_path") else {}),
         **({"single_gpu_same_n": same_n} if same_n else {}),
         "config": {
             "workload": f"all-pairs gravity step, N={n} bodies, {'fp64' if f64 else 'fp32'}, {'Plummer' if args.init == 1 else 'reference-cube'} init seed 12345, "
@@ -699,7 +743,7 @@ def main():
             "launch": info,
             "masses": ("Plummer: every body 1/N" if args.init == 1 and args.masses == "init" else "Plummer positions, masses uniform over a decade (total 1)"
                        if args.init == 1 else "the reference's fill_with_random4 range"),
-            **({"equal_mass": equal_mass} if equal_mass else {}),
+            "equal_mass": equal_mass,
             "gflops_at_20_flop_per_pair": value * FLOP_PER_PAIR / 1e9,
             **({"fp32_vs_fp64": fp_diff} if fp_diff else {}),
             **({"comm_rank0": comm} if comm else {}),
@@ -712,16 +756,12 @@ def main():
             "peak": peak,
             "unit": "TFLOP/s",
             "frac": achieved / peak,
-            # which pair arithmetic `frac` was measured on, and the GENERAL path (what unequal masses, e.g. the reference's own
-            # fill_with_random4 bodies, get) of the same run beside it: the >= 70 % target is to be read on the general path
-            "frac_path": ("equal-mass path (the bench's Plummer bodies all carry 1/N): 20 FLOP x N^2 interactions applied; the kernel executes 14 instead of "
-                          "16 packed ops per two pair evaluations" if equal_mass and equal_mass["path_taken"] else "general pair arithmetic"),
-            **({"frac_general_path": equal_mass["general_path"]["frac_of_peak_at_20_flop"], "general_path_kernel_ms_per_step": equal_mass["general_path"].get("kernel_ms_per_step"),
-                "frac_general_path_source": equal_mass["general_path"]["frac_source"]}
-               if equal_mass and equal_mass.get("general_path") else
-               {"frac_general_path": achieved / peak} if not (equal_mass and equal_mass["path_taken"]) else {}),
-            # BASELINE.md 3 asks for the 78.6 TF line too: the fp32 vector rate without packed (two-per-lane) instructions
-            **({"frac_of_unpacked_fp32_peak_78_6_tf": achieved / 78.6} if not f64 else {}),
+            # which pair arithmetic `frac` was measured on (default: the general one — the figure the >= 70 % target is read on), and the
+            # equal-mass path of the same run beside it when the bodies all carry one mass
+            "frac_path": ("equal-mass path (the bodies all carry one mass): 20 FLOP x N^2 interactions applied; the kernel executes 14 instead of "
+                          "16 packed ops per two pair evaluations" if equal_mass["path_taken"] else "general pair arithmetic"),
+            **({"frac_equal_mass": equal_mass["equal_mass_path"]["frac_of_peak_at_20_flop"], "equal_mass_kernel_ms_per_step": equal_mass["equal_mass_path"]["kernel_ms_per_step"],
+                "frac_equal_mass_source": equal_mass["equal_mass_path"]["frac_source"]} if equal_mass.get("equal_mass_path") else {}),
             "traffic": traffic,
             **({"traffic_source": traffic_source} if traffic_source else {}),
             **({"traffic_note": traffic_note} if traffic_note else {}),
@@ -745,9 +785,9 @@ def main():
                      "achieved/frac: 20 FLOP x interactions applied (N^2, the metric's convention: SURVEY.md 8d's per-unit figure x the units one launch processes); "
                      "achieved_evaluated/frac_evaluated: 20 FLOP x pair evaluations actually EXECUTED (the symmetric kernel evaluates each unordered pair once and "
                      "applies it to both bodies) — the figure to read as ALU work done per second" +
-                     ("; the bodies all carry the same mass, so the kernel took its equal-mass path (14 instead of 16 packed ops per two pair evaluations: the common "
-                      "mass is factored out of the sums and applied once per stored partial sum) — config.equal_mass.general_path is the same run with that path off"
-                      if equal_mass and equal_mass["path_taken"] else "")),
+                     ("; the bodies all carry the same mass and --equal-mass asked for the library's default, so the kernel took its equal-mass path (14 instead of 16 "
+                      "packed ops per two pair evaluations: the common mass is factored out of the sums and applied once per stored partial sum)"
+                      if equal_mass["path_taken"] else "; the timed steps ran the general pair arithmetic (the headline does not depend on the input's masses)")),
         },
     }
     if rank == 0:

@@ -217,12 +217,14 @@ int nbody_ctx_set_graph(nbody_ctx* ctx, int mode);
  * steps of the system. The knobs apply to every size the context is used with afterwards. */
 int nbody_ctx_autotune(nbody_ctx* ctx, const nbody_float4* d_bodies, int n, int steps_per_trial, int* out_choice,
                        double* out_us_per_step);
-/* nbody_simulate() — the default context — does this by itself, per size: the first call with n within a quarter of a built-in
- * switch-over size (8192, 45056, 160000) measures the decompositions once on scratch copies of the caller's bodies (trials of
- * about 10 ms each) and keeps the built-in choice unless another one is more than 3 % faster; later calls with that n use what was
- * found (results are bit-identical to forcing that decomposition through the knobs). Off with NBODY_NO_AUTOTUNE=1 in the
- * environment, or as soon as any shape knob of the default context is set. nbody_ctx_autotuned reports what was found for n:
- * choice as above, 0 = built-in kept, -1 = not measured; the two timings in microseconds per step. */
+/* nbody_simulate() — the default context — measures NOTHING by default: a caller that never asked for tuning (the reference's loop,
+ * main.cpp:146-156) gets the built-in decomposition, the same low-order bits on every machine and a first call without trial steps.
+ * With NBODY_AUTOTUNE=1 in the environment the first call with n within a quarter of a built-in switch-over size (8192, 45056,
+ * 160000) measures the decompositions once on scratch copies of the caller's bodies (trials of about 10 ms each) and keeps the
+ * built-in choice unless another one wins clearly and repeatably (nbody_autotune_decide); later calls with that n use what was found
+ * (results are bit-identical to forcing that decomposition through the knobs). Setting any shape knob of the default context
+ * switches the measurement off. nbody_ctx_autotuned reports what was found for n: choice as above, 0 = built-in kept, -1 = not
+ * measured; the two timings in microseconds per step. */
 int nbody_ctx_autotuned(nbody_ctx* ctx, int n, int* out_choice, double* out_us_builtin, double* out_us_best);
 /* Pins what nbody_simulate() uses for n bodies instead of measuring (a caller that wants the same decomposition, hence the same
  * low-order bits, on every machine): choice 0 = built-in, an id of nbody_ctx_autotune = that decomposition, -1 = forget n. */

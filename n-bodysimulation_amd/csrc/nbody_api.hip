@@ -2004,10 +2004,14 @@ bool near_switch_over(int n)
     return false;
 }
 
-bool autotune_disabled()
+// Measuring inside nbody_simulate() is OPT-IN (NBODY_AUTOTUNE=1 in the environment, looked at on each eligible call so that a host
+// program may set it after loading the library): a caller that never asked for tuning — the reference's loop, main.cpp:146-156 —
+// gets the built-in decomposition, hence the same low-order bits on every machine, and a first call that costs no measurement.
+// profiles/r04_autotune_probe.jsonl: the built-in choice was kept at all 13 sizes measured.
+bool autotune_enabled()
 {
-    static const bool off = [] { const char* e = std::getenv("NBODY_NO_AUTOTUNE"); return e && *e && *e != '0'; }();
-    return off;
+    const char* e = std::getenv("NBODY_AUTOTUNE");
+    return e && *e && *e != '0';
 }
 
 }  // namespace
@@ -2054,7 +2058,7 @@ int nbody_ctx_set_autotuned(nbody_ctx* c, int n, int choice)
 }
 
 // What nbody_simulate() found when it measured whole steps of n bodies on this context (see nbody.h). choice 0 = the built-in
-// decomposition was kept; -1 = this size has not been measured (not near a switch-over, NBODY_NO_AUTOTUNE, explicit knobs, or no call yet).
+// decomposition was kept; -1 = this size has not been measured (NBODY_AUTOTUNE not set, not near a switch-over, explicit knobs, or no call yet).
 int nbody_ctx_autotuned(nbody_ctx* c, int n, int* out_choice, double* out_us_builtin, double* out_us_best)
 {
     if (int rc = check_ctx(c)) return rc;
@@ -2118,6 +2122,21 @@ bool wait_host_word(nbody_ctx* c)
     }
 }
 
+// Are all three arrays ordinary device allocations (hipMalloc)? Looked up on every call that asks — a pointer value can come back
+// as another kind of memory after a free — which costs well under a microsecond on calls of 60 us and more (N > 8192).
+bool arrays_are_device_memory(const void* x, const void* a, const void* v)
+{
+    for (const void* p : {x, a, v}) {
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+            (void)hipGetLastError();   // not known to the runtime (pageable host memory under HMM, ...): not device memory
+            return false;
+        }
+        if (at.type != hipMemoryTypeDevice || at.isManaged) return false;
+    }
+    return true;
+}
+
 // One host_signal launch behind whatever is queued; then wait_host_word() can stand in for a stream synchronisation.
 void arm_host_signal(nbody_ctx* c)
 {
@@ -2155,12 +2174,13 @@ bool simulate_knobs_default(const nbody_ctx* c)
            c->tile == 0 && c->bpl == 0 && c->jsplit == 0 && c->use_graph == 0 && !c->timing;
 }
 
-// Near a built-in switch-over size the decomposition is MEASURED once per size on this device (scratch copies of the caller's
-// bodies, a few tens of milliseconds) instead of trusted: the sizes were measured on one pool of boxes with one compiler. The
-// built-in choice is kept unless another one is more than 3 % faster. NBODY_NO_AUTOTUNE=1, or any explicit knob, switches this off.
+// With NBODY_AUTOTUNE=1: near a built-in switch-over size the decomposition is MEASURED once per size on this device (scratch copies
+// of the caller's bodies, a few tens of milliseconds) instead of trusted: the sizes were measured on one pool of boxes with one
+// compiler. The built-in choice is kept unless another one wins clearly and repeatably (nbody_autotune_decide). Any explicit knob
+// switches this off. Without the variable nothing is measured: pinned choices (nbody_ctx_set_autotuned) still apply.
 int simulate_prepare_locked(nbody_ctx* c, const nbody_float4* d_bodies, int n)
 {
-    if (!(simulate_knobs_default(c) && n > 0 && d_bodies && !autotune_disabled() && near_switch_over(n) && !c->tuned.count(n))) return NBODY_OK;
+    if (!(simulate_knobs_default(c) && n > 0 && d_bodies && near_switch_over(n) && !c->tuned.count(n) && autotune_enabled())) return NBODY_OK;
     ON_DEVICE(c);
     FusedShape fs0{};
     const double est_us = 2.0 + (double)n * n / (fused_wanted(c, n, &fs0) ? 3.2e6 : 5.5e6);   // rough step time: a trial lasts about 10 ms
@@ -2208,9 +2228,13 @@ int nbody_simulate(nbody_float4* d_bodies, nbody_float4* d_accelerations, nbody_
     if (rc) return rc;
     if (!c->fdone_armed && !c->timing && n > 0 && c->fused_inplace != 0) {   // (mode 0 = round 3's behaviour, the A/B: a plain stream synchronisation)
         // the other paths (balanced runs, unit runs, block pairs: two or three launches per step): one tiny launch behind them writes
-        // the same host-mapped word — a launch boundary (1.5-2 us) instead of the 4 us a stream synchronisation costs over a spin
+        // the same host-mapped word — a launch boundary (1.5-2 us) instead of the 4 us a stream synchronisation costs over a spin.
+        // What makes the step's ordinary stores visible before that word is the release between two kernels of one stream: enough for
+        // DEVICE memory read next through a HIP copy or a kernel (the reference's arrays: cudaMalloc, main.cpp:275-283), not promised
+        // for host-mapped or managed arrays the CPU reads directly — those get the stream synchronisation and its system-scope release.
+        // (The in-place fused step above needs no such distinction: its results are system-scope stores, drained before its word.)
         ON_DEVICE(c);
-        arm_host_signal(c);
+        if (arrays_are_device_memory(d_bodies, d_accelerations, d_velocity)) arm_host_signal(c);
     }
     // simulate() is synchronous (kernel.cu:644). Waiting for the launch's own word costs about 4 us less per call than
     // hipStreamSynchronize (profiles/r04_sync_probe_*.txt); the stream synchronisation stays as the backstop (and reports errors).

@@ -1604,8 +1604,13 @@ __global__ void __launch_bounds__(64 * WV, MINW) step_fused(const FusedParams p)
         }
     }
     if (!INPLACE) return;
-    // Every workgroup counts itself out once its stores are complete (the barrier waits for them: s_waitcnt vmcnt(0), and a
-    // system-scope store is complete when memory has it); the workgroup that completes the count ends the launch.
+    // Every workgroup counts itself out once its stores are complete; the workgroup that completes the count ends the launch. The
+    // barrier alone does NOT wait for stores (the compiler puts s_waitcnt lgkmcnt(0) in front of s_barrier, nothing for vmcnt), so
+    // EVERY wave drains its own first: on gfx950 stores and atomics without return count in vmcnt, and a system-scope (sc0 sc1)
+    // store is acknowledged once memory has it. That orders, for each wave: results (and, on the fall-back path, xout, the fb mark and
+    // the 1 << 16 add) -> this wait -> barrier -> the workgroup's count-out below. The "memory" clobber keeps the compiler from moving a
+    // store across the wait; tests/test_isa_protocol.py checks the instruction in the shipped code object.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (w != 0) return;   // the first wave alone ends the workgroup's part (and, if it is the last workgroup's, the launch)
     unsigned before = 0;

@@ -153,6 +153,32 @@ def test_bench_defaults_name_the_baseline_configs():
     assert b.default_workload(4, 65536, "strong") == (65536, "strong")
 
 
+def test_bench_starts_its_own_ranks_when_not_under_the_launcher(tmp_path):
+    """`python bench.py --gpus G` (G > 1) without torch.distributed.run around it becomes the launcher of its own ranks — a child
+    process, the driver's own command line, rendezvous on 127.0.0.1 — instead of refusing to start. Without a GPU the ranks then
+    stop where every bench run stops here ("needs a GPU"), and the parent hands their non-zero exit code on."""
+    import importlib.util
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    cmd = b.rank_launch_command(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], 29400)
+    assert cmd[0] == sys.executable and cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29400"
+    assert cmd[-7:] == [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"]
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "launch through torch.distributed.run" not in src and "os.exec" not in src       # never a refusal, never an exec
+    import torch
+    if torch.cuda.is_available():
+        return                                                                                # (the GPU box runs the real thing: test_zz_rccl_rehearsal)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert r.returncode != 0 and "bench.py needs a GPU" in r.stderr, r.stderr[-2000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
 def test_symmetric_shape_choice_without_a_device():
     """nbody_plan_symmetric: the block shape the cost estimate picks at the sizes the sweeps were measured at
     (profiles/r02_shape_probe_{mid,large}.jsonl: the measured best at each), and how restrictions narrow it."""

@@ -1378,8 +1378,8 @@ def test_simulate_takes_the_in_place_step_and_its_host_word(nb, oracle):
         for k in range(1, 8):
             nb.engine.simulate(x, a, v)
             got = (x.cpu().numpy(), v.cpu().numpy(), a.cpu().numpy())    # straight after the call returns
-            if k == 1:     # near a switch-over size simulate() measures the decompositions first: the comparison run follows its choice
-                nb.engine.force_choice(ref.ctx, nb.engine.simulate_autotuned(n)["choice"])
+            if k == 1:     # nothing is measured unless the caller opts in (NBODY_AUTOTUNE): the built-in decomposition, on every machine
+                assert nb.engine.simulate_autotuned(n)["choice"] == -1
             ref.run(1)
             for p, q in zip(ref.state(), got):
                 assert np.array_equal(p, q), (n, k)
@@ -1388,11 +1388,63 @@ def test_simulate_takes_the_in_place_step_and_its_host_word(nb, oracle):
     assert np.abs(got[0] - xo)[:, :3].max() / 1e5 <= 1e-6
 
 
-def test_simulate_measures_the_decompositions_near_a_switch_over_size(nb, oracle):
-    """nbody_simulate() on the default context: the first call with n within a quarter of a built-in switch-over size (8192, 45056,
-    160000) times the decompositions on scratch copies and keeps the built-in one unless another is more than 3 % faster; sizes
-    elsewhere are not measured; the caller's bodies are only read by the measurement; what simulate() then computes is bit-identical
-    to a context forced onto the reported decomposition."""
+def test_simulate_on_host_mapped_arrays_read_by_the_cpu_at_once(nb):
+    """simulate() is synchronous (kernel.cu:644): whatever memory the caller's arrays live in, they are complete when the call
+    returns. Here all three arrays are HOST-MAPPED (nbody_malloc_host) and the CPU reads them directly — no copy, no HIP call in
+    between — right after every call: at N <= 8192 the in-place fused step ends with system-scope stores drained before its word;
+    above, the library sees that the arrays are not device memory and pays a stream synchronisation instead of its host word. The
+    bits must be those of the same steps on device arrays."""
+    import ctypes as C
+    lib = nb.load()
+    for n in (8192, 12288, 50000):
+        x0 = nb.engine.seeded_bodies(n, 0, 31)
+        ptrs, views = [], []
+        try:
+            for _ in range(3):
+                h = C.c_void_p()
+                nb.engine.check(lib.nbody_malloc_host(C.byref(h), 16 * n))
+                ptrs.append(h)
+                views.append(np.ctypeslib.as_array(C.cast(h, C.POINTER(C.c_float)), shape=(n, 4)))
+            hx, ha, hv = views
+            hx[:] = x0
+            ha[:] = 0
+            hv[:] = 0
+            ref = nb.engine.Simulation(x0)
+            for k in range(5):
+                nb.engine.check(lib.nbody_simulate(ptrs[0], ptrs[1], ptrs[2], n))
+                got = (hx.copy(), hv.copy(), ha.copy())        # the CPU's own loads, straight after the call returns
+                ref.run(1)
+                for p, q in zip(ref.state(), got):
+                    assert np.array_equal(p, q), (n, k)
+        finally:
+            for h in ptrs:
+                lib.nbody_free_host(h)
+
+
+def test_simulate_measures_nothing_unless_asked(nb, monkeypatch):
+    """The reference's loop never asked for tuning (main.cpp:146-156): by default simulate() measures nothing, even at a switch-over
+    size, and computes the bits of the built-in decomposition."""
+    monkeypatch.delenv("NBODY_AUTOTUNE", raising=False)
+    dev = torch.device("cuda", 0)
+    for n in (8190, 44000):
+        x0 = nb.engine.seeded_bodies(n, 0, 77)
+        x = torch.from_numpy(x0).to(dev)
+        v, a = torch.zeros_like(x), torch.zeros_like(x)
+        nb.engine.simulate(x, a, v)
+        nb.engine.simulate(x, a, v)
+        assert nb.engine.simulate_autotuned(n) == {"choice": -1, "us_builtin": 0.0, "us_best": 0.0}
+        ref = nb.engine.Simulation(x0)
+        ref.run(2)
+        for p, q in zip(ref.state(), (x.cpu().numpy(), v.cpu().numpy(), a.cpu().numpy())):
+            assert np.array_equal(p, q), n
+
+
+def test_simulate_measures_the_decompositions_near_a_switch_over_size(nb, oracle, monkeypatch):
+    """nbody_simulate() on the default context WITH NBODY_AUTOTUNE=1 (opt-in): the first call with n within a quarter of a built-in
+    switch-over size (8192, 45056, 160000) times the decompositions on scratch copies and keeps the built-in one unless another is
+    more than 3 % faster; sizes elsewhere are not measured; the caller's bodies are only read by the measurement; what simulate()
+    then computes is bit-identical to a context forced onto the reported decomposition."""
+    monkeypatch.setenv("NBODY_AUTOTUNE", "1")
     dev = torch.device("cuda", 0)
     for n, near in ((9000, True), (3000, False), (40000, True), (70000, False)):
         x0 = nb.engine.seeded_bodies(n, 0, 123)

@@ -1,0 +1,121 @@
+"""ISA-level guard on the one intra-launch, cross-workgroup protocol of the library: the in-place fused step.
+
+`step_fused<.., INPLACE = true>` (csrc/nbody_kernels.hip.h) lets the workgroup that completes the `finished` count write a host-mapped
+word on which `nbody_simulate` returns — the synchrony the reference gives its caller with cudaDeviceSynchronize
+(/root/reference/TestProject/kernel.cu:644; validation.cpp:77-81 copies the arrays back right after). That is only sound if EVERY
+storing wave has drained its result stores (s_waitcnt vmcnt(0): on gfx9-family parts stores count in vmcnt, and a system-scope
+`sc0 sc1` store is acknowledged by memory) BEFORE its workgroup's barrier and count-out (MI355X_MICROARCH.md, "every storing wave's
+s_waitcnt vmcnt(0), the workgroup's barrier, then the flag/counter"). The C++ source cannot promise that — the compiler places waits
+— and no amount of running shows the hole (it is a sub-microsecond window), so this test reads the instructions of the SHIPPED
+library: it unbundles libnbody_hip.so's gfx950 code object and disassembles it. No GPU needed.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+LIB = os.path.join(ROOT, "n-bodysimulation_amd", "libnbody_hip.so")
+
+INSN = re.compile(r"^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):")
+TARGET = re.compile(r"<[^>]*\+0x([0-9a-fA-F]+)>\s*$")
+
+
+def disassemble(lib, workdir):
+    """{mangled kernel name: [(address, mnemonic, operands, branch target address or None)]} of every gfx950 object bundled in lib"""
+    local = os.path.join(workdir, os.path.basename(lib))
+    shutil.copy(lib, local)                      # llvm-objdump --offloading writes the extracted objects beside its input
+    subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", local], check=True, capture_output=True, cwd=workdir)
+    objs = sorted(f for f in os.listdir(workdir) if "gfx950" in f)
+    assert objs, "no gfx950 code object in " + lib
+    funcs = {}
+    for o in objs:
+        txt = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--mcpu=gfx950", os.path.join(workdir, o)],
+                             check=True, capture_output=True, text=True).stdout
+        cur, base = None, 0
+        for ln in txt.splitlines():
+            m = re.match(r"^([0-9a-f]+) <(\S+)>:$", ln)
+            if m:
+                base, cur = int(m.group(1), 16), m.group(2)
+                funcs[cur] = []
+                continue
+            m = INSN.match(ln)
+            if m and cur:
+                t = TARGET.search(ln) if m.group(1).startswith(("s_cbranch", "s_branch")) else None
+                funcs[cur].append((int(m.group(3), 16), m.group(1), m.group(2), base + int(t.group(1), 16) if t else None))
+    return funcs
+
+
+@pytest.fixture(scope="module")
+def isa(nb, tmp_path_factory):
+    return disassemble(LIB, str(tmp_path_factory.mktemp("isa")))
+
+
+def _is_result_store(op, args):
+    return op.startswith(("global_store", "global_atomic", "flat_store", "flat_atomic", "buffer_store", "buffer_atomic"))
+
+
+def _drains_vm(op, args):
+    # "s_waitcnt vmcnt(0)" alone or with the other counters; a bare "s_waitcnt 0"-style encoding prints all three counters as (0)
+    return op == "s_waitcnt" and "vmcnt(0)" in args
+
+
+def check_drain_before_final_barrier(name, insns):
+    """every wave executes an s_waitcnt vmcnt(0) after its last result store and before the workgroup's final barrier"""
+    bar = max(k for k, (_, op, _, _) in enumerate(insns) if op == "s_barrier")
+    stores = [k for k in range(bar) if _is_result_store(insns[k][1], insns[k][2])]
+    assert stores, name + ": no result store in front of the final barrier"
+    waits = [k for k in range(stores[-1] + 1, bar) if _drains_vm(insns[k][1], insns[k][2])]
+    assert waits, (f"{name}: no s_waitcnt vmcnt(0) between the last result store (0x{insns[stores[-1]][0]:x}) and the final "
+                   f"s_barrier (0x{insns[bar][0]:x}): the count-out can overtake this wave's stores")
+    wk = waits[-1]
+    # ... on the path EVERY wave takes: nothing branches away between the wait and the barrier, nothing jumps in behind the wait
+    for k in range(wk, bar):
+        assert not insns[k][1].startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc")), (name, "branch between the drain and the barrier", insns[k])
+    lo, hi = insns[wk][0], insns[bar][0]
+    for addr, op, args, tgt in insns:
+        assert tgt is None or not (lo < tgt <= hi), (name, f"a branch at 0x{addr:x} enters between the drain and the barrier")
+    return bar
+
+
+def test_library_holds_the_in_place_fused_step_kernels(isa):
+    names = [n for n in isa if "step_fused" in n]
+    assert len([n for n in names if n.endswith("Lb1EEEvNS_11FusedParamsE")]) == 16, names
+    assert len([n for n in names if n.endswith("Lb0EEEvNS_11FusedParamsE")]) == 16, names
+
+
+def test_in_place_fused_step_drains_its_result_stores_before_the_count_out(isa):
+    names = sorted(n for n in isa if "step_fused" in n and n.endswith("Lb1EEEvNS_11FusedParamsE"))
+    assert names
+    for name in names:
+        insns = isa[name]
+        bar = check_drain_before_final_barrier(name, insns)
+        # behind the barrier: the `finished` count-out (an atomic with return), later the host-mapped word (the last system-scope
+        # 64-bit store of the kernel); between the repair path's stores and that word another full drain
+        outs = [k for k in range(bar, len(insns)) if insns[k][1].startswith("global_atomic_add") and "sc0" in insns[k][2]]
+        assert outs, (name, "no count-out atomic behind the final barrier")
+        words = [k for k in range(outs[0], len(insns)) if insns[k][1] == "global_store_dwordx2" and "sc0 sc1" in insns[k][2]]
+        assert words, (name, "no host-mapped word store")
+        word = words[-1]
+        repair = [k for k in words[:-1]]
+        if repair:
+            assert any(_drains_vm(insns[k][1], insns[k][2]) for k in range(repair[-1] + 1, word)), (name, "repair stores not drained before the host word")
+
+
+def test_the_checker_itself_sees_a_missing_drain():
+    """the rule is not vacuous: the round-4 code shape (stores, lgkm-only wait, barrier) fails it; the fixed shape passes"""
+    def mk(lines):
+        return [(0x100 + 4 * k, op, args, None) for k, (op, args) in enumerate(lines)]
+    bad = mk([("global_store_dwordx2", "v[8:9], v[10:11], off sc0 sc1"), ("global_atomic_add", "v0, v1, s[12:13] offset:4"),
+              ("s_waitcnt", "lgkmcnt(0)"), ("s_barrier", ""), ("s_waitcnt", "vmcnt(0)"), ("s_endpgm", "")])
+    with pytest.raises(AssertionError):
+        check_drain_before_final_barrier("bad", bad)
+    good = mk([("global_store_dwordx2", "v[8:9], v[10:11], off sc0 sc1"), ("s_waitcnt", "vmcnt(0) expcnt(0) lgkmcnt(0)"), ("s_barrier", ""), ("s_endpgm", "")])
+    check_drain_before_final_barrier("good", good)
+    skipped = mk([("s_cbranch_execz", "2"), ("global_store_dwordx2", "v[8:9], v[10:11], off sc0 sc1"), ("s_waitcnt", "vmcnt(0)"), ("s_nop", "0"), ("s_barrier", "")])
+    skipped[0] = (skipped[0][0], "s_cbranch_execz", "2", skipped[3][0])          # jumps in behind the wait: waves that skipped are fine, but flag the shape
+    with pytest.raises(AssertionError):
+        check_drain_before_final_barrier("skipped", skipped)

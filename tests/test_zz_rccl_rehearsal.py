@@ -62,6 +62,16 @@ def test_bench_multi_rank_over_real_rccl_on_one_gpu(fake_hosts, comm, world):
     assert line["config"]["comm_rank0"]["all_gather_ms_avg"] > 0 and line["config"]["comm_rank0"]["exchange_ms_avg"] > 0
 
 
+def test_bench_started_directly_launches_its_own_ranks(fake_hosts):
+    """`python bench.py --gpus 2 ...` with NO launcher in the command (the form the driver uses at --gpus 1, extended to G > 1): bench.py
+    starts `python -m torch.distributed.run ... bench.py --gpus 2 ...` as a child, relays its output and exit code. One line,
+    n_gpus 2, RCCL world 2; the headline is the general pair arithmetic, the equal-mass path of the same run beside it."""
+    line = run_bench([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--fake-hosts", "--bodies", "49152", "--steps", "2", "--warmup", "2", "--repeats", "2"])
+    check_multi_gpu_line(line, 2, 49152, "torch", distinct=False)
+    assert line["n_gpus"] == 2 and line["config"]["rccl"]["world"] == 2 and line["config"]["rccl"]["backend"] == "nccl"
+    assert line["equal_mass_path"] is False and line["roofline"]["frac_path"] == "general pair arithmetic"
+
+
 def test_bench_compares_stream_priorities_in_the_run(fake_hosts):
     """--comm-priority ab (what `auto` does on a GPU per rank with the library's communicator): a few untimed steps at normal and at
     the greatest stream priority, the faster kept on every rank, both timings in the line. Two ranks: the high priority is not
