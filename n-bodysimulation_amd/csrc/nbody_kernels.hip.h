@@ -601,11 +601,58 @@ __device__ __forceinline__ double next_row(const double v, const int addr)
 // first index of row I in the row-major list of block pairs (I < J): I*(2nb - I - 1)/2
 __device__ __forceinline__ int sym_row_offset(int I, int nb) { return (int)(((long)I * (2L * nb - I - 1)) / 2); }
 
-// block = 64*W threads. rect == 0: grid = nb*(nb-1)/2 pair tasks followed by nb diagonal tasks;
-// rect == 1: grid = nbi*nbj pair tasks. EQ: the equal-mass path (m0 = the common mass).
+// ONE rotation body for the three launch geometries (block = 64*W threads; EQ: the equal-mass path, m0 = the common mass):
+//   kSymGeneral  what the parameters say at run time: rect == 0 -> grid = nb*(nb-1)/2 pair tasks followed by nb diagonal tasks;
+//                rect == 1 -> grid = nbi*nbj pair tasks; the J run may start anywhere (j0) and wrap around (wrap);
+//   kSymSquare   the SQUARE case alone (one range against itself: rect == 0, no wrap, i0 == j0): same tasks, arithmetic and slab
+//                layout, without the run-time rectangle / wrap-around handling;
+//   kSymRect     the RECTANGULAR case alone (two disjoint ranges, rect == 1; the J run may wrap): what nbody_accel_cross launches —
+//                seven eighths of a rank's pairs in an 8-GPU run — without the triangular task list and the diagonal tasks.
+// The geometry is a COMPILE-TIME policy (`if constexpr`): each instantiation contains only its own control flow, and that is what the
+// specialised kernels are for — the instruction schedule of the rotation pass that hipcc finds for the simpler control flow, not a
+// different algorithm: square 2.7 % faster than general at N = 262144 (tools/symbench.hip, profiles/r03_symbench_rows.txt: 10.98 vs
+// 11.29 ms per launch on one box), rect 1-3 % on a two-halves launch (profiles/r03_symbench_rect.txt). Rounds 3-4 kept three copies of
+// this function; the fold keeps every kernel's instruction counts, registers and occupancy and measures within 0.5 % of the copies on
+// the same box (profiles/r05_one_rotation_body.txt). hipcc's register assignment in the rotation pass is sensitive to how this function
+// is WRITTEN, not only to what it computes: a first version (stores through lambdas, the equal-mass dispatch in a helper) had the same VALU
+// count and ran 2 % slower on the general path. Re-measure (tools/gpu_symbench_ab.sh) after touching it.
+enum SymCase : int { kSymGeneral = 0, kSymSquare = 1, kSymRect = 2 };
+
+// the I-side sums of a task (registers of the stationary bodies) -> slab J of the I range
+template <class M, bool EQ>
+__device__ __forceinline__ void sym_store_i(M& t, const SymParamsT<typename M::V4, typename M::S>& p, const int ibase, const int J,
+                                            const typename M::S m0)
+{
+    if (EQ) t.scale(m0);
+    typename M::V4* const out_i = p.slabs_i + (size_t)J * p.stride_i;
+#pragma unroll
+    for (int k = 0; k < M::BPL; ++k) {
+        const int i = ibase + k * 64;
+        if (i < p.ni) out_i[i] = t.acc(k);
+    }
+}
+
+// the J-side sums of a task (LDS) -> slab I of the J range
 template <class M, int W, bool EQ>
-__device__ __forceinline__ void force_sym_body_t(const SymParamsT<typename M::V4, typename M::S>& p, typename M::V4* const sh,
-                                                 const typename M::S m0)
+__device__ __forceinline__ void sym_store_j(const typename M::V4* const sh, const SymParamsT<typename M::V4, typename M::S>& p, const int I,
+                                            const int J, const int nj, const typename M::S m0)
+{
+    constexpr int B = 64 * W * M::BPL;
+    typename M::V4* const out_j = p.slabs_j + (size_t)I * p.stride_j;
+    for (int e = threadIdx.x; e < B; e += 64 * W) {
+        const int j = J * B + e;
+        if (j < nj) {
+            typename M::V4 a = sh[e];
+            if (EQ) { a.x *= m0; a.y *= m0; a.z *= m0; }
+            a.w = 0;
+            out_j[j] = a;
+        }
+    }
+}
+
+template <class M, int W, bool EQ, int CASE>
+__device__ __forceinline__ void force_sym_tile(const SymParamsT<typename M::V4, typename M::S>& p, typename M::V4* const sh,
+                                               const typename M::S m0)
 {
     constexpr int BPL = M::BPL;
     constexpr int B = 64 * W * BPL;
@@ -615,47 +662,58 @@ __device__ __forceinline__ void force_sym_body_t(const SymParamsT<typename M::V4
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int task = p.task0 + (int)blockIdx.x;
     int I, J;
     bool diag = false;
-    const int task = p.task0 + (int)blockIdx.x;
-    if (p.rect) {
+    bool rect = CASE == kSymRect;
+    if constexpr (CASE == kSymGeneral) rect = p.rect;
+    if (rect) {
         I = task % p.nbi;
         J = task / p.nbi;
     } else {
-        const int npair = p.nbi * (p.nbi - 1) / 2;
+        const int nb = p.nbi;
+        const int npair = nb * (nb - 1) / 2;
         diag = task >= npair;
         if (diag) {
             I = J = task - npair;
         } else {
-            const float q = 2.0f * p.nbi - 1.0f;
+            const float q = 2.0f * nb - 1.0f;
             I = (int)((q - __builtin_sqrtf(q * q - 8.0f * (float)task)) * 0.5f);
             if (I < 0) I = 0;
-            if (I > p.nbi - 2) I = p.nbi - 2;
-            while (I < p.nbi - 2 && sym_row_offset(I + 1, p.nbi) <= task) ++I;
-            while (I > 0 && sym_row_offset(I, p.nbi) > task) --I;
-            J = I + 1 + (task - sym_row_offset(I, p.nbi));
+            if (I > nb - 2) I = nb - 2;
+            while (I < nb - 2 && sym_row_offset(I + 1, nb) <= task) ++I;
+            while (I > 0 && sym_row_offset(I, nb) > task) --I;
+            J = I + 1 + (task - sym_row_offset(I, nb));
         }
     }
 
     // a body past the end of its range adds exactly +-0 to every real body (pad4), and what it collects itself is never stored
+    const V4* const xi = p.x + p.i0;
+    const int nj = CASE == kSymSquare ? p.ni : p.nj;
     M t;
     t.set_eps2(p.eps2);
     const int ibase = I * B + w * (64 * BPL) + lane;  // index within the I range
 #pragma unroll
     for (int k = 0; k < BPL; ++k) {
         const int i = ibase + k * 64;
-        t.set(k, i < p.ni ? p.x[p.i0 + i] : pad4<V4, EQ>());
+        // (the two spellings of one address are kept apart: hipcc schedules the rotation pass of the general kernel differently —
+        //  35 more s_nop per SymPacked<10> instantiation — when its I-side loads are written through the pre-offset pointer)
+        if constexpr (CASE == kSymGeneral) t.set(k, i < p.ni ? p.x[p.i0 + i] : pad4<V4, EQ>());
+        else t.set(k, i < p.ni ? xi[i] : pad4<V4, EQ>());
     }
-    const int jbase = J * B + lane;  // index within the J run
     const int rot = ((lane + 16) & 63) << 2;
+    const int jbase = J * B + lane;  // index within the J run
 
     auto fetch = [&](int c) {
         const int j = jbase + c * 64;
-        int ja = p.j0 + j;
-        if (p.wrap && ja >= p.wrap) ja -= p.wrap;
-        return j < p.nj ? p.x[ja] : pad4<V4, EQ>();
+        if constexpr (CASE == kSymSquare) {
+            return j < p.ni ? xi[j] : pad4<V4, EQ>();
+        } else {
+            int ja = p.j0 + j;
+            if (p.wrap && ja >= p.wrap) ja -= p.wrap;
+            return j < p.nj ? p.x[ja] : pad4<V4, EQ>();
+        }
     };
-
     if (!diag) {
 #pragma unroll
         for (int r = 0; r < BPL; ++r) sh[r * (64 * W) + tid] = zero4<V4>();  // B = BPL * 64*W
@@ -687,228 +745,45 @@ __device__ __forceinline__ void force_sym_body_t(const SymParamsT<typename M::V4
         }
         c = cn;
     }
-
-    if (EQ) t.scale(m0);
-    V4* const out_i = p.slabs_i + (size_t)J * p.stride_i;
-#pragma unroll
-    for (int k = 0; k < BPL; ++k) {
-        const int i = ibase + k * 64;
-        if (i < p.ni) out_i[i] = t.acc(k);
-    }
-    if (!diag) {
-        V4* const out_j = p.slabs_j + (size_t)I * p.stride_j;
-        for (int e = tid; e < B; e += 64 * W) {
-            const int j = J * B + e;
-            if (j < p.nj) {
-                V4 a = sh[e];
-                if (EQ) { a.x *= m0; a.y *= m0; a.z *= m0; }
-                a.w = 0;
-                out_j[j] = a;
-            }
-        }
+    // (the order of the two stores is part of what was measured per geometry: kept)
+    if constexpr (CASE == kSymGeneral) {
+        sym_store_i<M, EQ>(t, p, ibase, J, m0);
+        if (!diag) sym_store_j<M, W, EQ>(sh, p, I, J, nj, m0);
+    } else {
+        if (!diag) sym_store_j<M, W, EQ>(sh, p, I, J, nj, m0);
+        sym_store_i<M, EQ>(t, p, ibase, J, m0);
     }
 }
 
-template <class M, int W>
+// the equal-mass decision, once per workgroup (eq_uniform reads the verdict of nbk::mass_scan), then the tile
+#define NBK_SYM_KERNEL_BODY(CASE)                                                                    \
+    __shared__ typename M::V4 sh[64 * W * M::BPL];                                                   \
+    double m0 = 0.0;                                                                                 \
+    if (eq_uniform(p.eqm, p.eq_gen, &m0)) force_sym_tile<M, W, true, CASE>(p, sh, (typename M::S)m0); \
+    else force_sym_tile<M, W, false, CASE>(p, sh, (typename M::S)m0)
+
+template <class M, int W, int CASE>
 __device__ __forceinline__ void force_sym_body(const SymParamsT<typename M::V4, typename M::S>& p)
 {
-    __shared__ typename M::V4 sh[64 * W * M::BPL];
-    double m0 = 0.0;
-    if (eq_uniform(p.eqm, p.eq_gen, &m0)) force_sym_body_t<M, W, true>(p, sh, (typename M::S)m0);
-    else force_sym_body_t<M, W, false>(p, sh, (typename M::S)m0);
+    NBK_SYM_KERNEL_BODY(CASE);
 }
 
 template <class M, int W, int MINW = 1>
 __global__ void __launch_bounds__(64 * W, MINW) force_sym(const SymParamsT<typename M::V4, typename M::S> p)
 {
-    force_sym_body<M, W>(p);
-}
-
-// The SQUARE case alone (one range against itself: rect == 0, no wrap, i0 == j0): the same tasks, the same arithmetic and the same
-// slab layout as force_sym, without the run-time rectangle / wrap-around handling. Measured 2.7 % faster than the general kernel at
-// N = 262144 (tools/symbench.hip, profiles/r03_symbench_rows.txt: 10.98 vs 11.29 ms per launch on one box) — the instruction
-// schedule of the rotation pass that hipcc finds for the simpler control flow, not a different algorithm.
-template <class M, int W, bool EQ>
-__device__ __forceinline__ void force_sym_square_t(const SymParamsT<typename M::V4, typename M::S>& p, typename M::V4* const sh,
-                                                   const typename M::S m0)
-{
-    constexpr int BPL = M::BPL;
-    constexpr int B = 64 * W * BPL;
-    constexpr int NCH = B / 64;
-    using V4 = typename M::V4;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nb = p.nbi;
-    const int task = p.task0 + (int)blockIdx.x;
-    const int npair = nb * (nb - 1) / 2;
-    const bool diag = task >= npair;
-    int I, J;
-    if (diag) {
-        I = J = task - npair;
-    } else {
-        const float q = 2.0f * nb - 1.0f;
-        I = (int)((q - __builtin_sqrtf(q * q - 8.0f * (float)task)) * 0.5f);
-        if (I < 0) I = 0;
-        if (I > nb - 2) I = nb - 2;
-        while (I < nb - 2 && sym_row_offset(I + 1, nb) <= task) ++I;
-        while (I > 0 && sym_row_offset(I, nb) > task) --I;
-        J = I + 1 + (task - sym_row_offset(I, nb));
-    }
-    const V4* const x = p.x + p.i0;
-    const int n = p.ni;
-    M t;
-    t.set_eps2(p.eps2);
-    const int ibase = I * B + w * (64 * BPL) + lane;
-#pragma unroll
-    for (int k = 0; k < BPL; ++k) {
-        const int i = ibase + k * 64;
-        t.set(k, i < n ? x[i] : pad4<V4, EQ>());
-    }
-    const int rot = ((lane + 16) & 63) << 2;
-    const int jbase = J * B + lane;
-    auto fetch = [&](int c) {
-        const int j = jbase + c * 64;
-        return j < n ? x[j] : pad4<V4, EQ>();
-    };
-    if (!diag) {
-#pragma unroll
-        for (int r = 0; r < BPL; ++r) sh[r * (64 * W) + tid] = zero4<V4>();
-        __syncthreads();
-    }
-    int c = w * BPL;
-    V4 nxt = fetch(c);
-    for (int q = 0; q < NCH; ++q) {
-        V4 bj = nxt;
-        const int cn = (c + 1 == NCH) ? 0 : c + 1;
-        if (q + 1 < NCH) nxt = fetch(cn);
-        if (diag) {
-            V4 aj = zero4<V4>();
-            for (int ph = 0; ph < 4; ++ph) {
-                sym_row_pass<false, EQ>(t, bj, aj);
-                bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot);
-                if (!EQ) bj.w = next_row(bj.w, rot);
-            }
-        } else {
-            V4 aj = sh[c * 64 + lane];
-            for (int ph = 0; ph < 4; ++ph) {
-                sym_row_pass<true, EQ>(t, bj, aj);
-                bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot);
-                if (!EQ) bj.w = next_row(bj.w, rot);
-                aj.x = next_row(aj.x, rot); aj.y = next_row(aj.y, rot); aj.z = next_row(aj.z, rot);
-            }
-            sh[c * 64 + lane] = aj;
-            __syncthreads();
-        }
-        c = cn;
-    }
-    if (!diag) {
-        V4* const out_j = p.slabs_j + (size_t)I * p.stride_j;
-        for (int e = tid; e < B; e += 64 * W) {
-            const int j = J * B + e;
-            if (j < n) {
-                V4 a = sh[e];
-                if (EQ) { a.x *= m0; a.y *= m0; a.z *= m0; }
-                a.w = 0;
-                out_j[j] = a;
-            }
-        }
-    }
-    if (EQ) t.scale(m0);
-    V4* const out_i = p.slabs_i + (size_t)J * p.stride_i;
-#pragma unroll
-    for (int k = 0; k < BPL; ++k) {
-        const int i = ibase + k * 64;
-        if (i < n) out_i[i] = t.acc(k);
-    }
+    force_sym_body<M, W, kSymGeneral>(p);
 }
 
 template <class M, int W>
 __global__ void __launch_bounds__(64 * W, 1) force_sym_square(const SymParamsT<typename M::V4, typename M::S> p)
 {
-    __shared__ typename M::V4 sh[64 * W * M::BPL];
-    double m0 = 0.0;
-    if (eq_uniform(p.eqm, p.eq_gen, &m0)) force_sym_square_t<M, W, true>(p, sh, (typename M::S)m0);
-    else force_sym_square_t<M, W, false>(p, sh, (typename M::S)m0);
-}
-
-// The RECTANGULAR case alone (two disjoint ranges, rect == 1; the J run may wrap): what nbody_accel_cross launches — seven eighths of a
-// rank's pairs in an 8-GPU run. Same tasks, arithmetic and slab layout as force_sym with rect == 1, without the triangular task
-// list and the diagonal tasks of the square case.
-template <class M, int W, bool EQ>
-__device__ __forceinline__ void force_sym_rect_t(const SymParamsT<typename M::V4, typename M::S>& p, typename M::V4* const sh,
-                                                 const typename M::S m0)
-{
-    constexpr int BPL = M::BPL;
-    constexpr int B = 64 * W * BPL;
-    constexpr int NCH = B / 64;
-    using V4 = typename M::V4;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int task = p.task0 + (int)blockIdx.x;
-    const int I = task % p.nbi, J = task / p.nbi;
-    const V4* const xi = p.x + p.i0;
-    M t;
-    t.set_eps2(p.eps2);
-    const int ibase = I * B + w * (64 * BPL) + lane;
-#pragma unroll
-    for (int k = 0; k < BPL; ++k) {
-        const int i = ibase + k * 64;
-        t.set(k, i < p.ni ? xi[i] : pad4<V4, EQ>());
-    }
-    const int rot = ((lane + 16) & 63) << 2;
-    const int jbase = J * B + lane;
-    auto fetch = [&](int c) {
-        const int j = jbase + c * 64;
-        int ja = p.j0 + j;
-        if (p.wrap && ja >= p.wrap) ja -= p.wrap;
-        return j < p.nj ? p.x[ja] : pad4<V4, EQ>();
-    };
-#pragma unroll
-    for (int r = 0; r < BPL; ++r) sh[r * (64 * W) + tid] = zero4<V4>();
-    __syncthreads();
-    int c = w * BPL;
-    V4 nxt = fetch(c);
-    for (int q = 0; q < NCH; ++q) {
-        V4 bj = nxt;
-        const int cn = (c + 1 == NCH) ? 0 : c + 1;
-        if (q + 1 < NCH) nxt = fetch(cn);
-        V4 aj = sh[c * 64 + lane];
-        for (int ph = 0; ph < 4; ++ph) {
-            sym_row_pass<true, EQ>(t, bj, aj);
-            bj.x = next_row(bj.x, rot); bj.y = next_row(bj.y, rot); bj.z = next_row(bj.z, rot);
-            if (!EQ) bj.w = next_row(bj.w, rot);
-            aj.x = next_row(aj.x, rot); aj.y = next_row(aj.y, rot); aj.z = next_row(aj.z, rot);
-        }
-        sh[c * 64 + lane] = aj;
-        __syncthreads();
-        c = cn;
-    }
-    V4* const out_j = p.slabs_j + (size_t)I * p.stride_j;
-    for (int e = tid; e < B; e += 64 * W) {
-        const int j = J * B + e;
-        if (j < p.nj) {
-            V4 a = sh[e];
-            if (EQ) { a.x *= m0; a.y *= m0; a.z *= m0; }
-            a.w = 0;
-            out_j[j] = a;
-        }
-    }
-    if (EQ) t.scale(m0);
-    V4* const out_i = p.slabs_i + (size_t)J * p.stride_i;
-#pragma unroll
-    for (int k = 0; k < BPL; ++k) {
-        const int i = ibase + k * 64;
-        if (i < p.ni) out_i[i] = t.acc(k);
-    }
+    NBK_SYM_KERNEL_BODY(kSymSquare);
 }
 
 template <class M, int W>
 __global__ void __launch_bounds__(64 * W, 1) force_sym_rect(const SymParamsT<typename M::V4, typename M::S> p)
 {
-    __shared__ typename M::V4 sh[64 * W * M::BPL];
-    double m0 = 0.0;
-    if (eq_uniform(p.eqm, p.eq_gen, &m0)) force_sym_rect_t<M, W, true>(p, sh, (typename M::S)m0);
-    else force_sym_rect_t<M, W, false>(p, sh, (typename M::S)m0);
+    NBK_SYM_KERNEL_BODY(kSymRect);
 }
 
 // ---------------------------------------------------------------------------------------

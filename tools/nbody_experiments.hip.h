@@ -222,7 +222,7 @@ template <class M, int W, int WPS>
 __global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
 force_sym_wps(const SymParamsT<typename M::V4, typename M::S> p)
 {
-    force_sym_body<M, W>(p);
+    force_sym_body<M, W, kSymGeneral>(p);
 }
 
 // The same kernel compiled for exactly WPS waves per SIMD (the register allocator then fits that occupancy). Measured alternative,

@@ -19,6 +19,7 @@ ap.add_argument("--kernel", default="fast")
 ap.add_argument("--steps", type=int, default=6)
 ap.add_argument("--sym-waves", type=int, default=0)
 ap.add_argument("--sym-bpl", type=int, default=0)
+ap.add_argument("--no-equal-mass", action="store_true", help="the general pair arithmetic (what unequal masses get: bench.py's headline path)")
 ap.add_argument("worlds", type=int, nargs="*", default=[1, 2, 4, 8])
 args = ap.parse_args()
 L, lib = nbody_amd._lib, nbody_amd.load()
@@ -29,6 +30,8 @@ for G in args.worlds:
     ctx = nbody_amd.engine.Context(dt=0.01, kernel=kernel)
     if args.sym_waves or args.sym_bpl:
         ctx.set_symmetric_shape(args.sym_waves, args.sym_bpl)
+    if args.no_equal_mass:
+        ctx.set_equal_mass(0)
     g = L.ALL_GATHER_FN(lambda *a: 0)
     e = L.EXCHANGE_FN(lambda *a: 0)
     comm = L.Comm(None, g, e)
