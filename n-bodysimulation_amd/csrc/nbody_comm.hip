@@ -18,6 +18,8 @@ extern "C" {
 
 // ---- RCCL (librccl.so, loaded on first use) -------------------------------------------------------------------------
 
+}  // extern "C"
+
 namespace {
 
 struct RcclId { char internal[128]; };  // ncclUniqueId
@@ -96,6 +98,8 @@ int rccl_exchange(void* user, const nbody_shard_segment* send, int n_sends, cons
 }
 
 }  // namespace
+
+extern "C" {
 
 int nbody_comm_rccl_unique_id(void* out_128_bytes)
 {

@@ -4,7 +4,7 @@
 
 #include "nbody.h"
 
-int nbody_fail(int code, const char* fmt, ...);  // nbody_api.hip: sets nbody_last_error(), returns code
+int nbody_fail(int code, const char* fmt, ...);  // nbody_context.hip: sets nbody_last_error(), returns code
 
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \

@@ -2,7 +2,7 @@
 // collectives are callbacks (the built-in transports: nbody_comm.hip). The reference runs on one device only
 // (TestProject/kernel.cu:630, main.cpp:287); this is the build's own decomposition. The pair
 // arithmetic is entirely nbody_accel_range / nbody_accel_wrapped / nbody_accel_cross / nbody_integrate_range of
-// nbody_api.hip: this file only orders them on two streams.
+// nbody_step.hip: this file only orders them on two streams.
 #include "nbody_internal.hip.h"
 
 #include <cstdio>

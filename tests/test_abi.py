@@ -136,6 +136,17 @@ def test_launch_plan_is_always_buildable_and_covers_every_source(nb):
     assert _plan(nb, 262144, 262144)[:2] == (4, 2048) and _plan(nb, 8192, 8192)[:2] == (1, 256)
 
 
+def test_library_exports_no_stray_c_symbols(nb):
+    """Besides the `nbody_*` entry points of include/nbody.h the library may export C++-mangled names (kernel stubs, inline
+    members) and the HIP runtime's registration symbols — but no bare C identifier: a helper that leaks out as `accel_impl` or
+    `rccl_load` (an unnamed namespace nested inside an `extern "C"` block does exactly that) can collide with the host program's own."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", nb._lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    stray = [n for n in names if not (n.startswith("nbody_") or n.startswith("_Z") or n.startswith("__hip_") or n in ("_init", "_fini"))]
+    assert not stray, stray
+
+
 def test_bench_defaults_name_the_baseline_configs():
     """--gpus 1 runs configs[2] (N=262144); a dry look at what --gpus 8 would run: configs[3], N=1048576, strong."""
     import importlib.util

@@ -1,6 +1,6 @@
 """Compiler-dependent assumptions of the launch-shape logic, checked against the compiler's own report.
 
-`sym_cost` / `run_resolve` (n-bodysimulation_amd/csrc/nbody_api.hip) rank the symmetric kernel's block shapes with the number
+`sym_cost` / `run_resolve` (n-bodysimulation_amd/csrc/nbody_plan.hip) rank the symmetric kernel's block shapes with the number
 of waves per SIMD each instantiation's register allocation allows — a COMPILER OUTPUT, not a property of the source. A ROCm
 update that pushed `SymPacked<10>` past 256 VGPRs, or made any hot kernel spill to scratch, would halve the rate silently.
 `make -C n-bodysimulation_amd/csrc resources` compiles the product's device code with the product's flags plus
@@ -121,7 +121,7 @@ def test_fused_step_kernels_fit_one_workgroup_per_cu(kernels):
 
 def test_every_global_kernel_of_the_product_header_is_instantiated_by_the_library(kernels):
     """No orphans: every `__global__` template of the product's device header (csrc/nbody_kernels.hip.h) is instantiated by
-    libnbody_hip.so's sources (it shows up in the compiler's resource report of nbody_api.hip / nbody_shard.hip). Measured
+    libnbody_hip.so's sources (it shows up in the compiler's resource report of nbody_step.hip / nbody_shard.hip). Measured
     alternatives that nothing ships live in tools/nbody_experiments.hip.h, not in the product header."""
     hdr = open(os.path.join(ROOT, "n-bodysimulation_amd", "csrc", "nbody_kernels.hip.h")).read()
     declared = set(re.findall(r"__global__\s+void[^;{]*?\b([a-z_0-9]+)\s*\(const", hdr))

@@ -1,6 +1,6 @@
 """Developer probe: us/step and interactions/s across N for the one-sided kernel (auto shape) and every block shape
 of the symmetric kernel, queued steps (no host sync inside the timed loop). Feeds the FAST kernel's switch-over size
-and the symmetric block-shape choice in nbody_api.hip.  usage: smalln_probe.py [N ...]"""
+and the symmetric block-shape choice in nbody_plan.hip.  usage: smalln_probe.py [N ...]"""
 import json
 import os
 import sys
