@@ -26,6 +26,32 @@
  *     exception for C++ callers.)
  *   - nothing here falls back to a CPU path: without a usable HIP device every compute entry
  *     fails with NBODY_ERR_HIP.
+ *
+ * Which symbols are what (tests/test_abi.py keeps this map equal to the declarations below)
+ *   THE DROP-IN BOUNDARY — all a maintainer of the reference binds to put this library behind main.cpp / validation.cpp (20):
+ *     the step      nbody_simulate  nbody_last_error
+ *     memory        nbody_malloc_device  nbody_free_device  nbody_malloc_host  nbody_free_host  nbody_memcpy_h2d  nbody_memcpy_d2h
+ *                   nbody_device_synchronize
+ *     utils.h       nbody_fill_with_random4  nbody_fill_with_zeroes4  nbody_fill_with_zeroes3  nbody_random_float  nbody_print_device_prop
+ *     validation.h  nbody_verify_still_bodies  nbody_verify_equality4  nbody_verify_equality3
+ *     around it     nbody_simulate_prepare  nbody_default_ctx  nbody_simulate_host_legacy (the older snapshot's host-pointer boundary)
+ *   EXTENSIONS — no reference counterpart; a caller of the boundary never needs them (63):
+ *     contexts and knobs      nbody_ctx_create  nbody_ctx_destroy  nbody_ctx_set_params  nbody_ctx_set_kernel  nbody_ctx_set_symmetric_shape
+ *                             nbody_ctx_set_symmetric_runs  nbody_ctx_set_fused  nbody_ctx_set_fused_inplace  nbody_ctx_fused_inplace_stats
+ *                             nbody_ctx_set_equal_mass  nbody_ctx_equal_mass_verdict  nbody_ctx_set_workspace_limit  nbody_ctx_set_stream
+ *                             nbody_ctx_set_graph  nbody_ctx_reserve  nbody_ctx_sync  nbody_ctx_get  nbody_device_count
+ *     queued stepping, pieces nbody_step  nbody_step_f64  nbody_accel_range  nbody_accel_square_part  nbody_accel_wrapped  nbody_accel_cross
+ *                             nbody_integrate_range
+ *     measuring the machine   nbody_ctx_autotune  nbody_ctx_autotuned  nbody_ctx_set_autotuned  nbody_autotune_decide  nbody_ctx_timing
+ *                             nbody_ctx_timing_read
+ *     multi-GPU               nbody_shard_plan  nbody_shard_create  nbody_shard_destroy  nbody_shard_get_plan  nbody_shard_buffers
+ *                             nbody_shard_upload  nbody_shard_upload_velocity  nbody_shard_download  nbody_shard_step  nbody_shard_step_phase
+ *                             nbody_shard_sync  nbody_shard_comm_timing  nbody_shard_set_comm_priority  nbody_shard_comm_report
+ *                             nbody_comm_rccl_unique_id  nbody_comm_rccl_create  nbody_comm_rccl_destroy  nbody_comm_local_group_create
+ *                             nbody_comm_local_group_destroy  nbody_comm_local_create  nbody_comm_local_destroy  nbody_comm_local_abort
+ *     what would be launched  nbody_version  nbody_plan  nbody_plan_symmetric  nbody_plan_fused  nbody_plan_symmetric_occupancy
+ *                             nbody_ctx_launch_info  nbody_ctx_step_info  nbody_ctx_step_info_f64  nbody_ctx_square_info
+ *     seeded initial data     nbody_fill_seeded
  */
 #ifndef NBODY_H
 #define NBODY_H

@@ -136,6 +136,22 @@ def test_launch_plan_is_always_buildable_and_covers_every_source(nb):
     assert _plan(nb, 262144, 262144)[:2] == (4, 2048) and _plan(nb, 8192, 8192)[:2] == (1, 256)
 
 
+def test_header_says_which_symbols_are_the_boundary(nb):
+    """include/nbody.h lists, at its top, the drop-in boundary (what a maintainer of the reference binds) apart from the extensions:
+    the two lists together are exactly the declared symbols, and the boundary stays small."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "nbody.h")).read()
+    head = hdr[:hdr.index("#ifndef NBODY_H")]
+    b0, e0 = head.index("THE DROP-IN BOUNDARY"), head.index("EXTENSIONS")
+    boundary = set(re.findall(r"\bnbody_[a-z0-9_]+", head[b0:e0]))
+    extensions = set(re.findall(r"\bnbody_[a-z0-9_]+", head[e0:]))
+    declared = set(re.findall(r"^(?:int|float|void|const char\*) (nbody_[a-z0-9_]+)\(", hdr, re.M))
+    assert not (boundary & extensions)
+    assert boundary | extensions == declared == set(nb.exported_symbols()), (sorted(declared - boundary - extensions), sorted((boundary | extensions) - declared))
+    assert len(boundary) == 20 and {"nbody_simulate", "nbody_malloc_device", "nbody_memcpy_d2h", "nbody_fill_with_random4", "nbody_verify_still_bodies"} <= boundary
+    assert "(20)" in head[b0:e0] and "(%d)" % len(extensions) in head[e0:]
+
+
 def test_library_exports_no_stray_c_symbols(nb):
     """Besides the `nbody_*` entry points of include/nbody.h the library may export C++-mangled names (kernel stubs, inline
     members) and the HIP runtime's registration symbols — but no bare C identifier: a helper that leaks out as `accel_impl` or
