@@ -313,6 +313,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Multi-rank runs: RCCL prints a version banner to STDOUT when its first communicator comes up. The contract is ONE JSON line on
+    # stdout, so until that line is printed everything written to file descriptor 1 (by any library, from any language) goes to stderr.
+    real_stdout = None
+    if world > 1 or args.force_sharded:
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
+
+    def emit(obj) -> None:   # the run's one line (or the evidence of a failed self-check) on the real stdout
+        if real_stdout is not None:
+            sys.stdout.flush()
+            os.dup2(real_stdout, 1)
+        print(json.dumps(obj), flush=True)
     if args.fake_hosts:   # before RCCL is loaded
         os.environ["NCCL_HOSTID"] = f"nbody-bench-host-{rank}"
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
@@ -542,7 +555,7 @@ def main():
                                    "bodies": "the same positions, masses uniform over a decade (seed 777): mass-weighted J-side sums through the cross launches and the exchange"}}
         if not (rel_all <= 5e-5 and finite and rel_rand <= 5e-5 and finite_rand):
             if rank == 0:
-                print(json.dumps({"error": "multi_gpu_check failed", "multi_gpu_check": check, "rccl": rccl}), flush=True)
+                emit({"error": "multi_gpu_check failed", "multi_gpu_check": check, "rccl": rccl})
             raise SystemExit(3)
 
     phase("warmup")
@@ -578,7 +591,7 @@ def main():
         check["steps_checked"] = 1 + steps_before_timing
         if not equal:
             if rank == 0:
-                print(json.dumps({"error": "positions differ between ranks", "multi_gpu_check": check, "rccl": rccl}), flush=True)
+                emit({"error": "positions differ between ranks", "multi_gpu_check": check, "rccl": rccl})
             raise SystemExit(3)
         barrier()
 
@@ -797,7 +810,7 @@ def main():
                 if cpu.get("port_all_cores_value"):
                     cpu["gpu_over_cpu_all_cores"] = value / cpu["port_all_cores_value"]
             line["cpu_baseline"] = cpu
-        print(json.dumps(line), flush=True)
+        emit(line)
     if multi:
         # The line is out. Tear-down (shard, communicator, process group): if it has not finished within a minute the process says where
         # it hangs (phase + all Python stacks on stderr) and ends itself with a NON-ZERO exit code instead of leaving the launcher waiting.

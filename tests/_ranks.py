@@ -152,6 +152,7 @@ def run_bench(args, timeout=300):
     assert p.returncode == 0, err[-3000:]
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out[-2000:]          # rank 0 prints ONE JSON line, the other ranks nothing
+    assert [ln for ln in out.splitlines() if ln.strip()] == lines, out[:2000]   # ... and nothing else reaches stdout (RCCL's banner goes to stderr)
     return json.loads(lines[0])
 
 

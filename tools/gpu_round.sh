@@ -16,6 +16,11 @@
 #   pmc       PMC passes (one counter group per run, --kernel-trace only beside --pmc): the bench's general path, its equal-mass path
 #             (--equal-mass auto), and tools/sync_probe at N = 8192 (the two fused kernels); then tools/pmc_summary.py
 #   rehearse  bench.py --gpus 4 --fake-hosts at N = 1048576 (four RCCL ranks on the one GPU), both transports, started WITHOUT a launcher
+#   hunt      the 3-rank one-GPU RCCL rehearsal (bench.py --gpus 3 --fake-hosts, both transports, and the sharded-simulation test) over and over
+#             for up to 15 minutes, each run under a deadline with bench.py's stack dump armed: looks for the ONE stall seen in round 3
+#             (about one in thirty runs, no stack then). Stops at the first run that fails or stalls and keeps its stderr
+#   pkbank    tools/pkbank_mb: does the VGPR bank of a packed instruction's operands change its issue cost?
+#   multirank only the multi-rank files of the GPU suite (tests/test_gpu_sharded.py, tests/test_zz_rccl_rehearsal.py)
 #   contend   three processes stepping the reference's loop while a fourth keeps the GPU full; results compared byte for byte
 # build/sync_probe and build/symbench come from `make tools` (or the hipcc lines at the top of those files); an A/B partner for
 # `symab` is built from an older header:  git show <rev>:n-bodysimulation_amd/csrc/nbody_kernels.hip.h > /tmp/old/n-bodysimulation_amd/csrc/...
@@ -112,6 +117,16 @@ for stage in $STAGES; do
       [ $rc -eq 0 ] || break
       timeout -k 10 500 python bench.py --gpus 4 --fake-hosts --comm $comm --steps 3 --warmup 1 --repeats 3 > $OUT/rehearsal_4ranks_n1048576_$comm.json 2> $OUT/rehearsal_4ranks_n1048576_$comm.err; rc=$?
     done ;;
+  hunt)
+    t0=$SECONDS; k=0
+    while [ $((SECONDS - t0)) -lt 900 ] && [ $rc -eq 0 ]; do
+      k=$((k + 1)); comm=native; [ $((k % 2)) -eq 0 ] && comm=torch
+      NBODY_BENCH_STACKS_AFTER=70 timeout -k 10 100 python bench.py --gpus 3 --fake-hosts --comm $comm --bodies 49152 --steps 2 --warmup 2 --repeats 2 \
+          > $OUT/hunt_$k.json 2> $OUT/hunt_$k.err; rc=$?
+      echo "hunt run $k comm=$comm rc=$rc elapsed=$((SECONDS - t0))s $(python3 -c "import json,sys;d=json.loads([l for l in open('$OUT/hunt_$k.json') if l.startswith('{')][-1]);print('ms/step %.2f ag %.2f ex %.2f'%(d['ms_per_step'],d['config']['comm_rank0']['all_gather_ms_avg'],d['config']['comm_rank0']['exchange_ms_avg']))" 2>/dev/null)" | tee -a $OUT/hunt.txt
+      [ $rc -eq 0 ] && [ $k -gt 1 ] && find "$OUT" -maxdepth 1 -name "hunt_$((k - 1)).*" -delete
+    done
+    [ $rc -eq 0 ] || { echo "== FAILED RUN $k: stderr tail" | tee -a $OUT/hunt.txt; tail -120 $OUT/hunt_$k.err | tee -a $OUT/hunt.txt; } ;;
   contend)
     base="--n 8192 --steps 1500 --init libc --sync-each-step"
     $HEADLESS $base --dump $OUT/alone | tail -1 > $OUT/alone.json
@@ -128,6 +143,10 @@ for stage in $STAGES; do
     done
     find "$OUT" -maxdepth 1 -name "*.f4" -delete
     bad=$(grep -c "identical=NO" $OUT/summary.txt); say "mismatches: $bad"; [ "$bad" = 0 ] || rc=1 ;;
+  pkbank)
+    timeout -k 10 120 build/pkbank_mb > $OUT/pkbank_mb.txt 2>&1; rc=$?; cat $OUT/pkbank_mb.txt ;;
+  multirank)
+    timeout -k 10 900 python -m pytest tests/test_gpu_sharded.py tests/test_zz_rccl_rehearsal.py -q -x > $OUT/pytest_multirank.txt 2>&1; rc=$?; tail -5 $OUT/pytest_multirank.txt ;;
   *) say "unknown stage $stage"; exit 2 ;;
   esac
   say "$stage rc=$rc"
