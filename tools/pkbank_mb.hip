@@ -3,7 +3,8 @@
 // Why: two builds of the rotation kernel with the same instruction multiset but another register assignment differed by 2 % (round 5,
 // profiles/r05_one_rotation_body.txt). Each variant below issues 64 independent v_pk_fma_f32 per loop iteration from 8 waves per SIMD,
 // with the three source register PAIRS placed so that their first registers fall on chosen banks (register number mod 4), and reports
-// SIMD cycles per wave instruction (s_memtime ticks at 100 MHz are converted with the measured shader clock of a plain v_fma loop).
+// the time per wave instruction relative to a plain v_fma_f32 loop of the same shape.
+// Result (profiles/r05h_pkbank_mb.txt): 1.823-1.837 x v_fma_f32 for every placement - operand banks do not matter; the 2 % came from elsewhere.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
