@@ -1388,6 +1388,29 @@ def test_simulate_takes_the_in_place_step_and_its_host_word(nb, oracle):
     assert np.abs(got[0] - xo)[:, :3].max() / 1e5 <= 1e-6
 
 
+def test_simulate_results_read_from_another_stream_at_once(nb):
+    """the arrays are complete when simulate() returns, "whichever way the caller reads them next". Here the next
+    reader is a kernel on ANOTHER, non-blocking stream (nothing orders it behind the library's stream but the call having returned):
+    a device-side copy of all three arrays, taken right after every call, must carry the bits of the same steps run queued — at the
+    fused in-place step's sizes (the launch itself tells the host, while it is still winding down) and above (host word behind the step)."""
+    dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream(device=dev)
+    for n in (8192, 5000, 20000):
+        x0 = nb.engine.seeded_bodies(n, 0, 17)
+        x = torch.from_numpy(x0).to(dev)
+        v, a = torch.zeros_like(x), torch.zeros_like(x)
+        ref = nb.engine.Simulation(x0)
+        torch.cuda.synchronize(dev)
+        for k in range(6):
+            nb.engine.simulate(x, a, v)
+            with torch.cuda.stream(side):                      # no event, no synchronisation with the library's stream
+                cx, cv, ca = x.clone(), v.clone(), a.clone()
+            side.synchronize()
+            ref.run(1)
+            for p, q in zip(ref.state(), (cx.cpu().numpy(), cv.cpu().numpy(), ca.cpu().numpy())):
+                assert np.array_equal(p, q), (n, k)
+
+
 def test_simulate_on_host_mapped_arrays_read_by_the_cpu_at_once(nb):
     """simulate() is synchronous (kernel.cu:644): whatever memory the caller's arrays live in, they are complete when the call
     returns. Here all three arrays are HOST-MAPPED (nbody_malloc_host) and the CPU reads them directly — no copy, no HIP call in
