@@ -116,14 +116,15 @@ enum {
  * int N)` (kernel.cuh:2; kernel.cu:628-645): one step on the arrays of the caller's CURRENT device, in place
  * (the reference never selects a device either; the caller's current device is left unchanged),
  * SYNCHRONOUS (returns after the device has finished, like the reference's
- * cudaDeviceSynchronize at kernel.cu:644). d_accelerations is pure output. Uses DT / EPS2 of
+ * cudaDeviceSynchronize at kernel.cu:644): the three arrays are complete in memory when the call returns, whether they are read
+ * next by a copy, by a kernel on any stream or — host-mapped arrays — by the CPU. d_accelerations is pure output. Uses DT / EPS2 of
  * constants.h:25-26 and the FAST kernel unless the process-wide default context was
  * reconfigured through nbody_default_ctx(). N need not be a multiple of anything. */
 int nbody_simulate(nbody_float4* d_bodies, nbody_float4* d_accelerations, nbody_float4* d_velocity,
                    int n);
 /* Optional: everything nbody_simulate() would otherwise do inside its FIRST call for n bodies — workspaces, loading the device code
- * and, near a switch-over size, the measurement of the decompositions (nbody_ctx_autotuned below) on scratch copies of d_bodies, which
- * are only read. A caller that times its step loop (nbody_headless does) calls this before the loop; the reference has no
+ * and, only when NBODY_AUTOTUNE=1 is set, near a switch-over size, the measurement of the decompositions (nbody_ctx_autotuned below)
+ * on scratch copies of d_bodies, which are only read. A caller that times its step loop (nbody_headless does) calls this before the loop; the reference has no
  * counterpart (its first cudaLaunch pays the same kind of one-off cost inside the loop, main.cpp:146-156). */
 int nbody_simulate_prepare(const nbody_float4* d_bodies, int n);
 

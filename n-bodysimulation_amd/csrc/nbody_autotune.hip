@@ -2,10 +2,10 @@
 // nbody_ctx_autotune (explicit), and the opt-in measurement inside nbody_simulate() (NBODY_AUTOTUNE=1).
 #include "nbody_ctx.hip.h"
 
-using namespace nbi;
-
 #include <chrono>
 #include <cstdlib>
+
+using namespace nbi;
 
 // The rule by which a timing measurement may override the built-in decomposition (pure host logic: tests/test_abi.py). 1 = override.
 //  (a) the built-in choice, timed first and last, agrees with itself within 10 % (else the machine is not quiet);
@@ -203,7 +203,6 @@ int simulate_prepare_locked(nbody_ctx* c, const nbody_float4* d_bodies, int n)
 #pragma GCC visibility pop
 
 extern "C" {
-
 
 // Measures the decompositions that apply to whole steps of n bodies on THIS device and leaves the context's knobs (fused step,
 // runs mode, bodies per lane) on the fastest: the switch-over sizes compiled into the library were measured on one pool of

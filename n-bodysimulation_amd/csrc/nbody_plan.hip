@@ -2,9 +2,9 @@
 // through nbody_plan*, and through nbody_ctx_*_info for a context's current knobs.
 #include "nbody_ctx.hip.h"
 
-using namespace nbi;
-
 #include <cmath>
+
+using namespace nbi;
 
 #pragma GCC visibility push(hidden)
 namespace nbi {
