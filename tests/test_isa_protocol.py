@@ -105,6 +105,25 @@ def test_in_place_fused_step_drains_its_result_stores_before_the_count_out(isa):
             assert any(_drains_vm(insns[k][1], insns[k][2]) for k in range(repair[-1] + 1, word)), (name, "repair stores not drained before the host word")
 
 
+def test_in_place_results_and_the_host_words_are_system_scope_stores(isa):
+    """The host is told while the launch is still winding down, and eight XCDs' L2s are not coherent for ordinary stores: every
+    result store of the in-place kernels (x, v, a, the spare array, the marks) and the host-mapped word itself must go THROUGH the
+    L2 to memory (`sc0 sc1`); a plain `global_store_dwordx4` of a result would sit in one XCD's L2 when the host reads. Same for
+    the one-store kernel `host_signal` that stands in for a stream synchronisation above 8192 bodies."""
+    for name in sorted(n for n in isa if "step_fused" in n and n.endswith("Lb1EEEvNS_11FusedParamsE")):
+        stores = [(op, args) for _, op, args, _ in isa[name] if op.startswith("global_store")]
+        assert len(stores) >= 8, (name, stores)
+        for op, args in stores:
+            if op == "global_store_dword":      # the counters' reset and the running total: agent scope (sc1) or plain, device-side bookkeeping only
+                continue
+            assert "sc0 sc1" in args, (name, op, args)
+        assert not any(op in ("global_store_dwordx4", "global_store_dwordx3") for op, _ in stores), name
+    sig = [n for n in isa if "host_signal" in n]
+    assert len(sig) == 1
+    stores = [(op, args) for _, op, args, _ in isa[sig[0]] if op.startswith("global_store")]
+    assert len(stores) == 1 and stores[0][0] == "global_store_dwordx2" and "sc0 sc1" in stores[0][1], stores
+
+
 def test_the_checker_itself_sees_a_missing_drain():
     """the rule is not vacuous: the round-4 code shape (stores, lgkm-only wait, barrier) fails it; the fixed shape passes"""
     def mk(lines):
