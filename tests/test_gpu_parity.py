@@ -1413,19 +1413,25 @@ def test_simulate_results_read_from_another_stream_at_once(nb):
 
 def test_simulate_on_host_mapped_arrays_read_by_the_cpu_at_once(nb):
     """simulate() is synchronous (kernel.cu:644): whatever memory the caller's arrays live in, they are complete when the call
-    returns. Here all three arrays are HOST-MAPPED (nbody_malloc_host) and the CPU reads them directly — no copy, no HIP call in
-    between — right after every call: at N <= 8192 the in-place fused step ends with system-scope stores drained before its word;
+    returns. Here all three arrays are HOST-MAPPED (nbody_malloc_host) or MANAGED (hipMallocManaged) and the CPU reads them directly —
+    no copy, no HIP call in between — right after every call: at N <= 8192 the in-place fused step ends with system-scope stores drained before its word;
     above, the library sees that the arrays are not device memory and pays a stream synchronisation instead of its host word. The
     bits must be those of the same steps on device arrays."""
     import ctypes as C
     lib = nb.load()
-    for n in (8192, 12288, 50000):
+    hip = C.CDLL("libamdhip64.so")            # (already in the process: the library links it) for hipMallocManaged, which the C-ABI does not wrap
+    hip.hipMallocManaged.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+    hip.hipFree.argtypes = [C.c_void_p]
+    for n, kind in ((8192, "host"), (12288, "host"), (50000, "host"), (8192, "managed"), (20000, "managed")):
         x0 = nb.engine.seeded_bodies(n, 0, 31)
         ptrs, views = [], []
         try:
             for _ in range(3):
                 h = C.c_void_p()
-                nb.engine.check(lib.nbody_malloc_host(C.byref(h), 16 * n))
+                if kind == "host":
+                    nb.engine.check(lib.nbody_malloc_host(C.byref(h), 16 * n))
+                elif hip.hipMallocManaged(C.byref(h), 16 * n, 1) != 0:      # hipMemAttachGlobal
+                    pytest.skip("hipMallocManaged is not available on this box")
                 ptrs.append(h)
                 views.append(np.ctypeslib.as_array(C.cast(h, C.POINTER(C.c_float)), shape=(n, 4)))
             hx, ha, hv = views
@@ -1438,10 +1444,10 @@ def test_simulate_on_host_mapped_arrays_read_by_the_cpu_at_once(nb):
                 got = (hx.copy(), hv.copy(), ha.copy())        # the CPU's own loads, straight after the call returns
                 ref.run(1)
                 for p, q in zip(ref.state(), got):
-                    assert np.array_equal(p, q), (n, k)
+                    assert np.array_equal(p, q), (n, kind, k)
         finally:
             for h in ptrs:
-                lib.nbody_free_host(h)
+                lib.nbody_free_host(h) if kind == "host" else hip.hipFree(h)
 
 
 def test_simulate_measures_nothing_unless_asked(nb, monkeypatch):
