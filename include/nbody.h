@@ -35,7 +35,7 @@
  *     utils.h       nbody_fill_with_random4  nbody_fill_with_zeroes4  nbody_fill_with_zeroes3  nbody_random_float  nbody_print_device_prop
  *     validation.h  nbody_verify_still_bodies  nbody_verify_equality4  nbody_verify_equality3
  *     around it     nbody_simulate_prepare  nbody_default_ctx  nbody_simulate_host_legacy (the older snapshot's host-pointer boundary)
- *   EXTENSIONS — no reference counterpart; a caller of the boundary never needs them (63):
+ *   EXTENSIONS — no reference counterpart; a caller of the boundary never needs them (65):
  *     contexts and knobs      nbody_ctx_create  nbody_ctx_destroy  nbody_ctx_set_params  nbody_ctx_set_kernel  nbody_ctx_set_symmetric_shape
  *                             nbody_ctx_set_symmetric_runs  nbody_ctx_set_fused  nbody_ctx_set_fused_inplace  nbody_ctx_fused_inplace_stats
  *                             nbody_ctx_set_equal_mass  nbody_ctx_equal_mass_verdict  nbody_ctx_set_workspace_limit  nbody_ctx_set_stream
@@ -43,10 +43,11 @@
  *     queued stepping, pieces nbody_step  nbody_step_f64  nbody_accel_range  nbody_accel_square_part  nbody_accel_wrapped  nbody_accel_cross
  *                             nbody_integrate_range
  *     measuring the machine   nbody_ctx_autotune  nbody_ctx_autotuned  nbody_ctx_set_autotuned  nbody_autotune_decide  nbody_ctx_timing
- *                             nbody_ctx_timing_read
+ *                             nbody_ctx_timing_read  nbody_ctx_clock_read
  *     multi-GPU               nbody_shard_plan  nbody_shard_create  nbody_shard_destroy  nbody_shard_get_plan  nbody_shard_buffers
  *                             nbody_shard_upload  nbody_shard_upload_velocity  nbody_shard_download  nbody_shard_step  nbody_shard_step_phase
  *                             nbody_shard_sync  nbody_shard_comm_timing  nbody_shard_set_comm_priority  nbody_shard_comm_report
+ *                             nbody_shard_comm_report_ex
  *                             nbody_comm_rccl_unique_id  nbody_comm_rccl_create  nbody_comm_rccl_destroy  nbody_comm_local_group_create
  *                             nbody_comm_local_group_destroy  nbody_comm_local_create  nbody_comm_local_destroy  nbody_comm_local_abort
  *     what would be launched  nbody_version  nbody_plan  nbody_plan_symmetric  nbody_plan_fused  nbody_plan_symmetric_occupancy
@@ -116,8 +117,9 @@ enum {
  * int N)` (kernel.cuh:2; kernel.cu:628-645): one step on the arrays of the caller's CURRENT device, in place
  * (the reference never selects a device either; the caller's current device is left unchanged),
  * SYNCHRONOUS (returns after the device has finished, like the reference's
- * cudaDeviceSynchronize at kernel.cu:644): the three arrays are complete in memory when the call returns, whether they are read
- * next by a copy, by a kernel on any stream or — host-mapped arrays — by the CPU. d_accelerations is pure output. Uses DT / EPS2 of
+ * cudaDeviceSynchronize at kernel.cu:644): the three arrays are complete in memory when the call returns — tested for plain hipMalloc
+ * arrays read next by a copy or a kernel on any stream, and for host-mapped (hipHostMalloc) and managed arrays read by the CPU; any
+ * other kind of memory gets a full stream synchronisation. d_accelerations is pure output. Uses DT / EPS2 of
  * constants.h:25-26 and the FAST kernel unless the process-wide default context was
  * reconfigured through nbody_default_ctx(). N need not be a multiple of anything. */
 int nbody_simulate(nbody_float4* d_bodies, nbody_float4* d_accelerations, nbody_float4* d_velocity,
@@ -428,9 +430,9 @@ int nbody_shard_step(nbody_shard* shard, int steps);
  * 1 = force launches, 2 = start the exchange, 3 = add received sums + integrate. nbody_shard_step = 0,1,2,3 per step. */
 int nbody_shard_step_phase(nbody_shard* shard, int phase);
 int nbody_shard_sync(nbody_shard* shard);
-/* Per-step communication timing (events on the two streams): mean all-gather time and the part of it not hidden
- * behind the first half of the own-block pass; mean exchange time and the part of it not hidden behind the second
- * half. Any out pointer may be NULL. */
+/* Per-step communication timing (events on the two streams; a ring of 64 step records whose events are reused, each folded into
+ * running sums before its slot comes up again — memory does not grow with the number of timed steps). Enabling (or disabling)
+ * starts the statistics afresh. */
 int nbody_shard_comm_timing(nbody_shard* shard, int enable);
 /* Priority of the rank's communication stream: 0 = normal (the default), 1 = the greatest the device offers (RCCL's few
  * channel workgroups are then placed ahead of the queued force workgroups). Measured: with three or more processes
@@ -438,6 +440,18 @@ int nbody_shard_comm_timing(nbody_shard* shard, int enable);
  * processes); with a GPU per rank it is a knob to try (bench.py --comm native --comm-priority auto measures both).
  * The stream is made on first use; a later call synchronises both streams and replaces it. Call between steps. */
 int nbody_shard_set_comm_priority(nbody_shard* shard, int high);
+/* What the timed steps since nbody_shard_comm_timing(.., 1) add up to. Mean AND maximum over the steps — one late all-gather in
+ * twenty is invisible in a mean: the all-gather's time and the part of it not hidden behind the first half of the own-block pass
+ * (from the end of that pass to the end of the gather; 0 when the gather ended first); the exchange's time and the part not hidden
+ * behind the second half. nbody_shard_comm_report is the older, means-only form; any of its out pointers may be NULL. */
+typedef struct nbody_comm_report_t {
+    int steps;           /* timed steps begun */
+    int gathers, exchanges;   /* steps that carried an all-gather / an exchange (the first step after an upload has neither) */
+    int records_kept;    /* step records alive (<= 64) */
+    double gather_ms, gather_exposed_ms, exchange_ms, exchange_exposed_ms;                       /* means over those steps */
+    double gather_ms_max, gather_exposed_ms_max, exchange_ms_max, exchange_exposed_ms_max;       /* maxima over those steps */
+} nbody_comm_report_t;
+int nbody_shard_comm_report_ex(nbody_shard* shard, nbody_comm_report_t* out);
 int nbody_shard_comm_report(nbody_shard* shard, int* steps, double* gather_ms, double* gather_exposed_ms, double* exchange_ms,
                             double* exchange_exposed_ms);
 
@@ -480,12 +494,28 @@ int nbody_verify_equality4(const nbody_float4* h_v, const nbody_float4* h_x, int
 int nbody_verify_equality3(const nbody_float3* h_v, const nbody_float3* h_x, int n);
 
 /* ---- measurement ------------------------------------------------------------------------- */
-/* With timing on, every force-kernel launch made through this context is bracketed by a pair of
+/* With timing on (enable = 1), every force-kernel launch made through this context is bracketed by a pair of
  * hipEvents on the launch stream. nbody_ctx_timing_read() synchronises the stream, returns the
  * summed force-kernel time (ms) and the number of launches since the last read, and resets the
- * counters. (bench.py's roofline figure; costs two event records per launch.) */
+ * counters. (bench.py's roofline figure; costs two event records per launch.)
+ * enable = 2 adds the CLOCK: outside the event pair, in front of and behind the force launch, one tiny launch each reads shader-cycle
+ * counters (s_memtime, kept per CU) and the constant 100-MHz counter (s_memrealtime); the launch behind pairs the readings CU by CU and
+ * writes, per XCD, the shader cycles and 100-MHz ticks that elapsed into host-mapped memory — no stamp executes inside the measured
+ * kernel. nbody_ctx_clock_read() turns the records since the last read into: shader cycles that elapsed per force launch (mean over
+ * the XCDs; the two launch boundaries, a few microseconds, included), 100-MHz ticks per launch, and their ratio x 100 MHz = the shader
+ * clock held under THAT load — overall, and for the slowest / fastest XCD (the eight XCDs of one MI355X run 1.5-2 % apart). launches =
+ * timed launches with at least one XCD paired (at most 4096 between two reads; later ones go unstamped), unpaired = (launch, XCD)
+ * records in which no CU was seen by both stamps (0 expected on a GPU that runs nothing else). This is what separates "a slower box"
+ * from "slower code" in a bench line. */
+typedef struct nbody_clock_report {
+    int launches, xcds, unpaired;
+    double cycles_per_launch, cycles_per_launch_min, cycles_per_launch_max;
+    double ticks_per_launch;        /* 100-MHz ticks: x 1e-5 = milliseconds */
+    double sclk_mhz, sclk_mhz_min_xcd, sclk_mhz_max_xcd;
+} nbody_clock_report;
 int nbody_ctx_timing(nbody_ctx* ctx, int enable);
 int nbody_ctx_timing_read(nbody_ctx* ctx, double* force_ms, int* launches);
+int nbody_ctx_clock_read(nbody_ctx* ctx, nbody_clock_report* out);
 
 /* ---- diagnostics ------------------------------------------------------------------------- */
 const char* nbody_last_error(void);

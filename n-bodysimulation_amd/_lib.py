@@ -50,6 +50,22 @@ class Segment(C.Structure):       # nbody_shard_segment
     _fields_ = [("peer", C.c_int), ("offset", C.c_int), ("count", C.c_int), ("body0", C.c_int)]
 
 
+class ClockReport(C.Structure):
+    """include/nbody.h: nbody_clock_report"""
+    _fields_ = [("launches", C.c_int), ("xcds", C.c_int), ("unpaired", C.c_int),
+                ("cycles_per_launch", C.c_double), ("cycles_per_launch_min", C.c_double), ("cycles_per_launch_max", C.c_double),
+                ("ticks_per_launch", C.c_double),
+                ("sclk_mhz", C.c_double), ("sclk_mhz_min_xcd", C.c_double), ("sclk_mhz_max_xcd", C.c_double)]
+
+
+class CommReport(C.Structure):
+    """include/nbody.h: nbody_comm_report_t"""
+    _fields_ = [("steps", C.c_int), ("gathers", C.c_int), ("exchanges", C.c_int), ("records_kept", C.c_int),
+                ("gather_ms", C.c_double), ("gather_exposed_ms", C.c_double), ("exchange_ms", C.c_double), ("exchange_exposed_ms", C.c_double),
+                ("gather_ms_max", C.c_double), ("gather_exposed_ms_max", C.c_double), ("exchange_ms_max", C.c_double),
+                ("exchange_exposed_ms_max", C.c_double)]
+
+
 class ShardPlan(C.Structure):     # nbody_shard_plan_t
     _fields_ = [("rank", C.c_int), ("world", C.c_int), ("n_total", C.c_int), ("schedule", C.c_int),
                 ("shard", C.c_int), ("n_pad", C.c_int), ("i0", C.c_int), ("i1", C.c_int),
@@ -123,8 +139,10 @@ _SIGNATURES = {
     "nbody_shard_comm_timing": (C.c_int, [_p, C.c_int]),
     "nbody_shard_set_comm_priority": (C.c_int, [_p, C.c_int]),
     "nbody_shard_comm_report": (C.c_int, [_p, C.POINTER(C.c_int)] + [C.POINTER(C.c_double)] * 4),
+    "nbody_shard_comm_report_ex": (C.c_int, [_p, C.POINTER(CommReport)]),
     "nbody_ctx_timing": (C.c_int, [_p, C.c_int]),
     "nbody_ctx_timing_read": (C.c_int, [_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "nbody_ctx_clock_read": (C.c_int, [_p, C.POINTER(ClockReport)]),
     "nbody_step_f64": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_double, C.c_double]),
     "nbody_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "nbody_malloc_device": (C.c_int, [C.POINTER(_p), C.c_size_t]),

@@ -151,15 +151,56 @@ int ensure_inbox(nbody_ctx* c, const BalShape& b)
     return NBODY_OK;
 }
 
+// the clock stamps' device scratch and host-mapped per-launch records (allocated on first use)
+static int ensure_cstamp(nbody_ctx* c)
+{
+    if (c->cdelta && c->cscratch) return NBODY_OK;
+    const size_t bytes = kClockCapLaunches * sizeof(nbk::ClockDelta);
+    if (!c->cscratch) {
+        const hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->cscratch), nbk::kClockBeginWgs * sizeof(nbk::ClockStamp));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            c->cscratch = nullptr;
+            return fail(NBODY_ERR_NOMEM, "cannot allocate the clock-stamp scratch: %s", hipGetErrorString(e));
+        }
+    }
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&c->cdelta), bytes, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->cdelta_dev), c->cdelta, 0);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (c->cdelta) (void)hipHostFree(c->cdelta);
+        c->cdelta = c->cdelta_dev = nullptr;
+        return fail(NBODY_ERR_NOMEM, "cannot allocate the clock-stamp records (%zu bytes): %s", bytes, hipGetErrorString(e));
+    }
+    std::memset(c->cdelta, 0, bytes);
+    return NBODY_OK;
+}
+
+// Called in front of and behind every timed force launch. Events alone (timing on), or — clock option — a clock stamp OUTSIDE
+// the event pair on either side: clock_begin, event, <force launch>, event, clock_end. The events keep measuring the force kernel alone;
+// the two stamps bracket it plus two launch boundaries (a few microseconds: 0.05 % of a 10-ms launch).
 int time_mark(nbody_ctx* c)
 {
     if (!c->timing) return NBODY_OK;
+    const bool begin = (c->events_used & 1) == 0;
+    if (begin && c->clock_stamps) {
+        c->clock_pair_open = false;
+        if (c->cdelta_used < kClockCapLaunches && ensure_cstamp(c) == NBODY_OK) {
+            if (int rc = launch_clock_stamp(c, nullptr)) return rc;
+            c->clock_pair_open = true;
+        }
+    }
     if (c->events_used == c->events.size()) {
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
         c->events.push_back(e);
     }
     HIP_TRY(hipEventRecord(c->events[c->events_used++], c->stream));
+    if (!begin && c->clock_pair_open) {
+        c->clock_pair_open = false;
+        if (int rc = launch_clock_stamp(c, c->cdelta_dev + c->cdelta_used)) return rc;
+        ++c->cdelta_used;
+    }
     return NBODY_OK;
 }
 
@@ -252,6 +293,8 @@ int nbody_ctx_destroy(nbody_ctx* c)
     if (c->xalt) (void)hipFree(c->xalt);
     if (c->fsync) (void)hipFree(c->fsync);
     if (c->fhost) (void)hipHostFree(c->fhost);
+    if (c->cdelta) (void)hipHostFree(c->cdelta);
+    if (c->cscratch) (void)hipFree(c->cscratch);
     if (c->eqm) (void)hipFree(c->eqm);
     if (c->legacy_buf) (void)hipFree(c->legacy_buf);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
@@ -462,9 +505,14 @@ int nbody_ctx_set_graph(nbody_ctx* c, int mode)
 int nbody_ctx_timing(nbody_ctx* c, int enable)
 {
     if (int rc = check_ctx(c)) return rc;
+    if (enable < 0 || enable > 2) return fail(NBODY_ERR_CONFIG, "timing mode must be 0 (off), 1 (events) or 2 (events + clock stamps)");
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->timing = enable != 0;
+    c->clock_stamps = enable == 2;
+    c->clock_pair_open = false;
     c->events_used = 0;
+    if (c->cdelta && c->cdelta_used) std::memset(c->cdelta, 0, c->cdelta_used * sizeof(nbk::ClockDelta));
+    c->cdelta_used = 0;
     return NBODY_OK;
 }
 
@@ -481,6 +529,54 @@ int nbody_ctx_timing_read(nbody_ctx* c, double* force_ms, int* launches)
     if (force_ms) *force_ms = total;
     if (launches) *launches = (int)(c->events_used / 2);
     c->events_used = 0;
+    return NBODY_OK;
+}
+
+int nbody_ctx_clock_read(nbody_ctx* c, nbody_clock_report* out)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (!out) return fail(NBODY_ERR_INVALID, "null out");
+    *out = nbody_clock_report{};
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const size_t launches = c->cdelta_used;
+    double cyc[8] = {0}, tk[8] = {0};
+    long seen[8] = {0};
+    double sum_c = 0, sum_t = 0, lmin = 0, lmax = 0;
+    long complete = 0, missing = 0;
+    for (size_t l = 0; l < launches; ++l) {
+        const nbk::ClockDelta& d = c->cdelta[l];
+        double lc = 0, lt = 0;
+        int ln = 0;
+        for (int x = 0; x < 8; ++x) {
+            if (!d.dcycles[x] || !d.dticks[x]) { ++missing; continue; }   // no CU of this XCD was seen by both stamps of this launch
+            cyc[x] += (double)d.dcycles[x]; tk[x] += (double)d.dticks[x]; ++seen[x];
+            lc += (double)d.dcycles[x]; lt += (double)d.dticks[x]; ++ln;
+        }
+        if (!ln) continue;
+        lc /= ln; lt /= ln;                                              // this launch: mean over the XCDs that answered
+        sum_c += lc; sum_t += lt; ++complete;
+        if (lmin == 0 || lc < lmin) lmin = lc;
+        if (lc > lmax) lmax = lc;
+    }
+    out->launches = (int)complete;
+    out->unpaired = (int)missing;
+    if (complete) {
+        out->cycles_per_launch = sum_c / (double)complete;
+        out->ticks_per_launch = sum_t / (double)complete;
+        out->sclk_mhz = sum_c / sum_t * 100.0;
+        out->cycles_per_launch_min = lmin;
+        out->cycles_per_launch_max = lmax;
+        for (int x = 0; x < 8; ++x) {
+            if (!seen[x]) continue;
+            ++out->xcds;
+            const double f = cyc[x] / tk[x] * 100.0;
+            if (out->sclk_mhz_min_xcd == 0 || f < out->sclk_mhz_min_xcd) out->sclk_mhz_min_xcd = f;
+            if (f > out->sclk_mhz_max_xcd) out->sclk_mhz_max_xcd = f;
+        }
+    }
+    if (c->cdelta && launches) std::memset(c->cdelta, 0, launches * sizeof(nbk::ClockDelta));
+    c->cdelta_used = 0;
+    c->clock_pair_open = false;
     return NBODY_OK;
 }
 

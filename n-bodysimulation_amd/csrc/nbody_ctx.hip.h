@@ -29,6 +29,7 @@ static_assert(sizeof(nbody_double4) == sizeof(double4), "double4 layout");
 constexpr int kMaxSplit = 64;
 constexpr int kGraphMaxN = 16384;  // below this a step is a few tens of microseconds: launch-bound
 constexpr int kGraphChunk = 32;    // steps per graph launch
+constexpr size_t kClockCapLaunches = 4096;   // timed launches whose clock stamps are kept between two reads (further ones go unstamped)
 
 struct nbody_ctx {
     int device = 0;
@@ -82,6 +83,13 @@ struct nbody_ctx {
     bool timing = false;
     std::vector<hipEvent_t> events;  // start/stop pairs around force launches
     size_t events_used = 0;
+    // nbody_ctx_timing(.., 2): every timed launch is also bracketed by nbk::clock_begin / clock_end (shader cycles + 100-MHz ticks per XCD)
+    bool clock_stamps = false;
+    bool clock_pair_open = false;          // clock_begin of the current launch was issued (its clock_end follows)
+    nbk::ClockStamp* cscratch = nullptr;   // device: kClockBeginWgs records, rewritten by every clock_begin
+    nbk::ClockDelta* cdelta = nullptr;     // host-mapped: one record per timed launch, kClockCapLaunches of them, zero = not written
+    nbk::ClockDelta* cdelta_dev = nullptr;
+    size_t cdelta_used = 0;                // launches stamped since the last nbody_ctx_clock_read
     // hipGraph of `graph_chunk` (force, integrate) pairs for launch-bound small systems, cached
     // for one set of arguments
     int use_graph = 0;   // -1 auto (n <= kGraphMaxN), 0 never (default: measured neutral, see nbody.h), 1 always
@@ -171,6 +179,7 @@ constexpr int kMaxDevices = 64;
 extern std::recursive_mutex g_default_mu;   // serialises the entry points that work on the default contexts
 
 // nbody_step.hip
+int launch_clock_stamp(nbody_ctx* c, nbk::ClockDelta* d_out);   // d_out == nullptr: nbk::clock_begin, else nbk::clock_end into *d_out
 void load_device_code();   // makes the runtime load this library's device code now (milliseconds), not inside a first timed step
 
 // nbody_autotune.hip

@@ -611,7 +611,8 @@ __device__ __forceinline__ int sym_row_offset(int I, int nb) { return (int)(((lo
 // this function; the fold keeps every kernel's instruction counts, registers and occupancy and measures within 0.5 % of the copies on
 // the same box (profiles/r05_one_rotation_body.txt). hipcc's register assignment in the rotation pass is sensitive to how this function
 // is WRITTEN, not only to what it computes: a first version (stores through lambdas, the equal-mass dispatch in a helper) had the same VALU
-// count and ran 2 % slower on the general path. Re-measure (tools/gpu_symbench_ab.sh) after touching it.
+// count and ran 2 % slower on the general path. Re-measure (`tools/gpu_round.sh <tag> symab`, table by
+// tools/symbench_ab_table.py) after touching it.
 enum SymCase : int { kSymGeneral = 0, kSymSquare = 1, kSymRect = 2 };
 
 // the I-side sums of a task (registers of the stationary bodies) -> slab J of the I range
@@ -1233,6 +1234,40 @@ __global__ void __launch_bounds__(256) copy_bodies(float4* __restrict__ dst, con
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] = src[i];
+}
+
+// The clock a timed force launch ran at, WITHOUT a stamp inside the measured kernel (MI355X_MICROARCH.md: per-segment stamps cost
+// cycles): clock_begin in front of the launch and clock_end behind it, on its stream (nbi::time_mark with the clock option on).
+// clock_begin: sixteen waves note their CU's shader-cycle counter and the 100-MHz counter in device scratch. clock_end: one wave
+// per workgroup, enough workgroups to land on every CU; a wave that finds a begin record of its own CU writes the two differences
+// to the launch's host-mapped record under its XCD (CUs of one XCD give the same difference: any writer will do). Cycles / ticks x
+// 100 MHz = the shader clock that XCD held while the force kernel ran; the interval includes the two launch boundaries.
+__device__ __forceinline__ ClockStamp read_clock()
+{
+    ClockStamp s;
+    s.cycles = __builtin_amdgcn_s_memtime();
+    s.ticks = __builtin_amdgcn_s_memrealtime();
+    s.xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;   // HW_REG_XCC_ID, bits 3:0
+    s.hw_id = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID: cu_id 11:8, sh_id 12, se_id 15:13
+    return s;
+}
+
+__global__ void __launch_bounds__(64) clock_begin(ClockStamp* scratch)
+{
+    if (threadIdx.x == 0) scratch[blockIdx.x] = read_clock();
+}
+
+__global__ void __launch_bounds__(64) clock_end(const ClockStamp* scratch, ClockDelta* out)
+{
+    if (threadIdx.x != 0) return;
+    const ClockStamp e = read_clock();
+    for (int k = 0; k < kClockBeginWgs; ++k) {
+        const ClockStamp b = scratch[k];
+        if (b.xcc != e.xcc || ((b.hw_id ^ e.hw_id) & 0xff00u) != 0) continue;   // another CU: its counter started elsewhere
+        __hip_atomic_store(out->dcycles + e.xcc, e.cycles - b.cycles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(out->dticks + e.xcc, e.ticks - b.ticks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+    }
 }
 
 // One 64-bit word to host-mapped memory: launched behind the last kernel of a synchronous call (nbody_simulate on the paths that are

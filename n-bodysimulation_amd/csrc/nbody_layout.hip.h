@@ -121,6 +121,24 @@ inline bool bal_plan(int n, int bpl, int workers_target, int wv, BalLayout* out)
 // Device words of the in-place protocol.
 // kFusedFinished counts workgroups in its low half and fall-back waves in its high half (a wave's mark precedes its workgroup's
 // count, so the workgroup that completes the count reads both in the one value its atomic returns: one round trip, not two).
+// The clock stamps around a timed force launch (nbk::clock_begin / clock_end). s_memtime is a free-running counter of SHADER cycles
+// (MI355X_MICROARCH.md: "tick = shader cycle") kept PER CU: the CUs of one XCD count at the same rate from different starting values
+// (measured, tools/clock_probe.hip: same-XCD CUs agree to 1e-6 over a launch, tail idleness included; different XCDs run 1.5-2 % apart),
+// so a difference is only meaningful between two readings on the SAME CU. s_memrealtime is the constant 100-MHz counter, the same on
+// every XCD to within a fraction of a microsecond.
+//   ClockStamp  what one wave read in front of the launch (device scratch; xcc = HW_REG_XCC_ID, hw_id = HW_REG_HW_ID: se / sh / cu)
+//   ClockDelta  per timed launch, per XCD: shader cycles and 100-MHz ticks between the two stamps on one CU of that XCD (host-mapped;
+//               0 = no CU of that XCD was seen by both stamps)
+struct ClockStamp {
+    unsigned long long cycles, ticks;
+    unsigned xcc, hw_id;
+};
+struct ClockDelta {
+    unsigned long long dcycles[8], dticks[8];
+};
+constexpr int kClockBeginWgs = 16;   // workgroups of the stamp in front: consecutive workgroup ids go to consecutive XCDs, two CUs each
+constexpr int kClockEndWgs = 256;    // workgroups of the stamp behind: lands on every CU of an otherwise idle chip, finds its partner by CU
+
 enum FusedSync : int { kFusedReaders = 0, kFusedFinished = 1, kFusedFallbacksTotal = 2, kFusedSyncWords = 4 };
 
 }  // namespace nbk

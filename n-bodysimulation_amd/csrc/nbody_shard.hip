@@ -39,16 +39,22 @@ struct nbody_shard {
     hipEvent_t ev_integrated = nullptr, ev_gathered = nullptr, ev_cross = nullptr, ev_exchanged = nullptr;
     bool fresh = true;          // positions consistent on every rank (just uploaded): the first step skips the all-gather
     bool gather_posted = false;
-    // communication timing
+    // communication timing: a RING of kTimedRing step records whose events are reused; a record is folded into the running sums
+    // (mean AND maximum over the steps: one late all-gather in twenty is invisible in a mean) before its events are recorded again
     bool timing = false;
     struct StepEvents {
         hipEvent_t g0, g1, local_done, x0, x1, own_done;
-        bool gathered, exchanged;
+        bool gathered, exchanged, local_marked, own_marked, open;
     };
-    std::vector<StepEvents> timed;
+    std::vector<StepEvents> ring;
+    size_t timed_steps = 0;     // steps begun with timing on since nbody_shard_comm_timing(.., 1)
+    size_t cur = 0;             // ring slot of the step being issued
+    nbody_comm_report_t agg{};  // what the folded records add up to (the *_ms fields hold SUMS until a report divides them)
 };
 
 namespace {
+
+constexpr size_t kTimedRing = 64;
 
 int new_event(hipEvent_t* e, bool timing)
 {
@@ -91,25 +97,81 @@ int make_comm_stream(nbody_shard* s, bool high)
 
 int ensure_comm(nbody_shard* s) { return s->comm ? NBODY_OK : make_comm_stream(s, s->comm_high); }
 
+// Adds one finished step record to the running sums (waits for its events: a record is folded either when its ring slot comes up
+// again, kTimedRing steps later, or by a report).
+int fold_step(nbody_shard* s, nbody_shard::StepEvents& t)
+{
+    if (!t.open) return NBODY_OK;
+    nbody_comm_report_t& a = s->agg;
+    float ms = 0;
+    if (t.gathered) {
+        HIP_TRY(hipEventSynchronize(t.g1));
+        HIP_TRY(hipEventElapsedTime(&ms, t.g0, t.g1));
+        a.gather_ms += ms;
+        if (ms > a.gather_ms_max) a.gather_ms_max = ms;
+        // not hidden = from the end of the own-block pass to the end of the all-gather (0 when the gather ended first)
+        double e = 0;
+        if (t.local_marked) {
+            HIP_TRY(hipEventSynchronize(t.local_done));
+            if (hipEventElapsedTime(&ms, t.local_done, t.g1) == hipSuccess && ms > 0) e = ms;
+            else (void)hipGetLastError();
+        }
+        a.gather_exposed_ms += e;
+        if (e > a.gather_exposed_ms_max) a.gather_exposed_ms_max = e;
+        ++a.gathers;
+    }
+    if (t.exchanged) {
+        HIP_TRY(hipEventSynchronize(t.x1));
+        HIP_TRY(hipEventElapsedTime(&ms, t.x0, t.x1));
+        a.exchange_ms += ms;
+        if (ms > a.exchange_ms_max) a.exchange_ms_max = ms;
+        // not hidden = from the end of the second half of the own block to the end of the exchange
+        double e = 0;
+        if (t.own_marked) {
+            HIP_TRY(hipEventSynchronize(t.own_done));
+            if (hipEventElapsedTime(&ms, t.own_done, t.x1) == hipSuccess && ms > 0) e = ms;
+            else (void)hipGetLastError();
+        }
+        a.exchange_exposed_ms += e;
+        if (e > a.exchange_exposed_ms_max) a.exchange_exposed_ms_max = e;
+        ++a.exchanges;
+    }
+    t.open = t.gathered = t.exchanged = t.local_marked = t.own_marked = false;
+    return NBODY_OK;
+}
+
+// the ring slot of the step about to be issued: a new record while the ring grows, otherwise the oldest one, folded first
+int begin_timed_step(nbody_shard* s)
+{
+    const size_t slot = s->timed_steps % kTimedRing;
+    if (slot == s->ring.size()) {
+        nbody_shard::StepEvents ev{};
+        for (hipEvent_t* e : {&ev.g0, &ev.g1, &ev.local_done, &ev.x0, &ev.x1, &ev.own_done})
+            if (int rc = new_event(e, true)) return rc;
+        s->ring.push_back(ev);
+    } else if (int rc = fold_step(s, s->ring[slot])) {
+        return rc;
+    }
+    s->ring[slot].open = true;
+    s->cur = slot;
+    ++s->timed_steps;
+    return NBODY_OK;
+}
+
 int phase_gather(nbody_shard* s)
 {
     const nbody_shard_plan_t& p = s->plan;
     s->gather_posted = false;
-    if (s->timing) {
-        nbody_shard::StepEvents ev{};
-        for (hipEvent_t* e : {&ev.g0, &ev.g1, &ev.local_done, &ev.x0, &ev.x1, &ev.own_done})
-            if (int rc = new_event(e, true)) return rc;
-        s->timed.push_back(ev);
-    }
+    if (s->timing) if (int rc = begin_timed_step(s)) return rc;
     if (p.world == 1 || s->fresh) return NBODY_OK;
     if (int rc = ensure_comm(s)) return rc;
     HIP_TRY(hipStreamWaitEvent(s->comm, s->ev_integrated, 0));  // the own block was advanced by the last integrate
-    if (s->timing) HIP_TRY(hipEventRecord(s->timed.back().g0, s->comm));
+    if (s->timing) HIP_TRY(hipEventRecord(s->ring[s->cur].g0, s->comm));
     if (s->cb.all_gather(s->cb.user, nb(s->x), p.shard, static_cast<void*>(s->comm)) != 0)
         return nbody_fail(NBODY_ERR_HIP, "all-gather callback failed on rank %d", p.rank);
     if (s->timing) {
-        HIP_TRY(hipEventRecord(s->timed.back().g1, s->comm));
-        s->timed.back().gathered = true;
+        HIP_TRY(hipEventRecord(s->ring[s->cur].g1, s->comm));
+        s->ring[s->cur].gathered = true;
     }
     HIP_TRY(hipEventRecord(s->ev_gathered, s->comm));
     s->gather_posted = true;
@@ -128,7 +190,7 @@ int phase_compute(nbody_shard* s)
     if (p.schedule == NBODY_SCHEDULE_ONESIDED) {
         // own block against itself while the positions of the others are still on their way
         if (int rc = nbody_accel_range(c, nb(s->x), nb(s->a), p.i0, p.i1, p.i0, p.i1, 0)) return rc;
-        if (s->timing && s->gather_posted) HIP_TRY(hipEventRecord(s->timed.back().local_done, s->compute));
+        if (s->timing && s->gather_posted) HIP_TRY(hipEventRecord(s->ring[s->cur].local_done, s->compute));
         if (s->gather_posted) HIP_TRY(hipStreamWaitEvent(s->compute, s->ev_gathered, 0));
         if (p.world == 1) return NBODY_OK;
         // everybody else in one launch: sources i1, i1+1, ... wrapping round to i0-1
@@ -138,7 +200,7 @@ int phase_compute(nbody_shard* s)
     // second (phase_finish) hides the exchange. The sums land in `a` in a fixed order: cross launches, own block, received.
     HIP_TRY(hipMemsetAsync(s->a, 0, (size_t)p.shard * sizeof(float4), s->compute));
     if (int rc = nbody_accel_square_part(c, nb(s->x), nb(s->a), p.i0, p.i1, 1, 0, p.world > 1 ? 2 : 1)) return rc;
-    if (s->timing && s->gather_posted) HIP_TRY(hipEventRecord(s->timed.back().local_done, s->compute));
+    if (s->timing && s->gather_posted) { HIP_TRY(hipEventRecord(s->ring[s->cur].local_done, s->compute)); s->ring[s->cur].local_marked = true; }
     if (s->gather_posted) HIP_TRY(hipStreamWaitEvent(s->compute, s->ev_gathered, 0));
     if (p.world == 1) return NBODY_OK;
     for (int l = 0; l < p.n_launches; ++l) {
@@ -157,12 +219,12 @@ int phase_exchange(nbody_shard* s)
     if (p.world == 1 || p.schedule != NBODY_SCHEDULE_SYMMETRIC || p.shard == 0) return NBODY_OK;
     if (int rc = ensure_comm(s)) return rc;
     HIP_TRY(hipStreamWaitEvent(s->comm, s->ev_cross, 0));
-    if (s->timing) HIP_TRY(hipEventRecord(s->timed.back().x0, s->comm));
+    if (s->timing) HIP_TRY(hipEventRecord(s->ring[s->cur].x0, s->comm));
     if (s->cb.exchange(s->cb.user, p.send, p.n_sends, nb(s->jbuf), p.recv, p.n_recvs, nb(s->rbuf), static_cast<void*>(s->comm)) != 0)
         return nbody_fail(NBODY_ERR_HIP, "exchange callback failed on rank %d", p.rank);
     if (s->timing) {
-        HIP_TRY(hipEventRecord(s->timed.back().x1, s->comm));
-        s->timed.back().exchanged = true;
+        HIP_TRY(hipEventRecord(s->ring[s->cur].x1, s->comm));
+        s->ring[s->cur].exchanged = true;
     }
     HIP_TRY(hipEventRecord(s->ev_exchanged, s->comm));
     return NBODY_OK;
@@ -174,7 +236,7 @@ int phase_finish(nbody_shard* s)
     if (p.shard == 0) return NBODY_OK;
     if (p.schedule == NBODY_SCHEDULE_SYMMETRIC && p.world > 1) {  // second half of the own block (+ its slab sum), while the exchange runs
         if (int rc = nbody_accel_square_part(s->ctx, nb(s->x), nb(s->a), p.i0, p.i1, 1, 1, 2)) return rc;
-        if (s->timing && !s->timed.empty() && s->timed.back().exchanged) HIP_TRY(hipEventRecord(s->timed.back().own_done, s->compute));
+        if (s->timing && !s->ring.empty() && s->ring[s->cur].exchanged) { HIP_TRY(hipEventRecord(s->ring[s->cur].own_done, s->compute)); s->ring[s->cur].own_marked = true; }
     }
     if (p.world > 1 && p.schedule == NBODY_SCHEDULE_SYMMETRIC) {
         HIP_TRY(hipStreamWaitEvent(s->compute, s->ev_exchanged, 0));
@@ -250,7 +312,7 @@ int nbody_shard_destroy(nbody_shard* s)
         if (ptr) (void)hipFree(ptr);
     for (hipEvent_t ev : {s->ev_integrated, s->ev_gathered, s->ev_cross, s->ev_exchanged})
         if (ev) (void)hipEventDestroy(ev);
-    for (auto& t : s->timed)
+    for (auto& t : s->ring)
         for (hipEvent_t ev : {t.g0, t.g1, t.local_done, t.x0, t.x1, t.own_done})
             if (ev) (void)hipEventDestroy(ev);
     if (s->comm) (void)hipStreamDestroy(s->comm);
@@ -372,10 +434,10 @@ int nbody_shard_comm_timing(nbody_shard* s, int enable)
 {
     if (int rc = check_shard(s)) return rc;
     if (int rc = nbody_shard_sync(s)) return rc;
-    for (auto& t : s->timed)
-        for (hipEvent_t ev : {t.g0, t.g1, t.local_done, t.x0, t.x1, t.own_done})
-            if (ev) (void)hipEventDestroy(ev);
-    s->timed.clear();
+    for (auto& t : s->ring) t.open = t.gathered = t.exchanged = t.local_marked = t.own_marked = false;   // (the events stay: reused)
+    s->timed_steps = 0;
+    s->cur = 0;
+    s->agg = nbody_comm_report_t{};
     s->timing = enable != 0;
     return NBODY_OK;
 }
@@ -399,35 +461,33 @@ int nbody_shard_set_comm_priority(nbody_shard* s, int high)
     return NBODY_OK;
 }
 
+int nbody_shard_comm_report_ex(nbody_shard* s, nbody_comm_report_t* out)
+{
+    if (int rc = check_shard(s)) return rc;
+    if (!out) return nbody_fail(NBODY_ERR_INVALID, "null out");
+    if (int rc = nbody_shard_sync(s)) return rc;
+    DeviceScope scope(s->device);
+    for (auto& t : s->ring)
+        if (int rc = fold_step(s, t)) return rc;
+    nbody_comm_report_t r = s->agg;   // sums so far; the report divides
+    r.steps = (int)s->timed_steps;
+    r.records_kept = (int)s->ring.size();
+    if (r.gathers) { r.gather_ms /= r.gathers; r.gather_exposed_ms /= r.gathers; }
+    if (r.exchanges) { r.exchange_ms /= r.exchanges; r.exchange_exposed_ms /= r.exchanges; }
+    *out = r;
+    return NBODY_OK;
+}
+
 int nbody_shard_comm_report(nbody_shard* s, int* steps, double* gather_ms, double* gather_exposed_ms, double* exchange_ms,
                             double* exchange_exposed_ms)
 {
-    if (int rc = check_shard(s)) return rc;
-    if (int rc = nbody_shard_sync(s)) return rc;
-    double g = 0, ge = 0, x = 0, xe = 0;
-    int ng = 0, nx = 0;
-    for (auto& t : s->timed) {
-        float ms = 0;
-        if (t.gathered) {
-            HIP_TRY(hipEventElapsedTime(&ms, t.g0, t.g1));
-            g += ms;
-            // not hidden = from the end of the own-block pass to the end of the all-gather (0 when the gather ended first)
-            if (hipEventElapsedTime(&ms, t.local_done, t.g1) == hipSuccess && ms > 0) ge += ms;
-            ++ng;
-        }
-        if (t.exchanged) {
-            HIP_TRY(hipEventElapsedTime(&ms, t.x0, t.x1));
-            x += ms;
-            // not hidden = from the end of the second half of the own block to the end of the exchange
-            if (hipEventElapsedTime(&ms, t.own_done, t.x1) == hipSuccess && ms > 0) xe += ms;
-            ++nx;
-        }
-    }
-    if (steps) *steps = (int)s->timed.size();
-    if (gather_ms) *gather_ms = ng ? g / ng : 0.0;
-    if (gather_exposed_ms) *gather_exposed_ms = ng ? ge / ng : 0.0;
-    if (exchange_ms) *exchange_ms = nx ? x / nx : 0.0;
-    if (exchange_exposed_ms) *exchange_exposed_ms = nx ? xe / nx : 0.0;
+    nbody_comm_report_t r{};
+    if (int rc = nbody_shard_comm_report_ex(s, &r)) return rc;
+    if (steps) *steps = r.steps;
+    if (gather_ms) *gather_ms = r.gather_ms;
+    if (gather_exposed_ms) *gather_exposed_ms = r.gather_exposed_ms;
+    if (exchange_ms) *exchange_ms = r.exchange_ms;
+    if (exchange_exposed_ms) *exchange_exposed_ms = r.exchange_exposed_ms;
     return NBODY_OK;
 }
 

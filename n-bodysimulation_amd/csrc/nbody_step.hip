@@ -247,6 +247,14 @@ int launch_sym(nbody_ctx* c, const SymShape& y, const nbk::SymParams& p, int nta
 #pragma GCC visibility push(hidden)
 namespace nbi {
 
+int launch_clock_stamp(nbody_ctx* c, nbk::ClockDelta* d_out)
+{
+    if (!d_out) nbk::clock_begin<<<nbk::kClockBeginWgs, 64, 0, c->stream>>>(c->cscratch);
+    else nbk::clock_end<<<nbk::kClockEndWgs, 64, 0, c->stream>>>(c->cscratch, d_out);
+    HIP_TRY(hipGetLastError());
+    return NBODY_OK;
+}
+
 void load_device_code()
 {
     hipFuncAttributes attr;
@@ -777,8 +785,11 @@ bool wait_host_word(nbody_ctx* c)
     }
 }
 
-// Are all three arrays ordinary device allocations (hipMalloc)? Looked up on every call that asks — a pointer value can come back
-// as another kind of memory after a free — which costs well under a microsecond on calls of 60 us and more (N > 8192).
+// Are all three arrays ORDINARY device allocations — plain hipMalloc: device memory, not managed, no allocation flags (fine-grained,
+// uncached and signal memory from hipExtMallocWithFlags carry flags and take the stream synchronisation, like host-mapped and managed
+// arrays)? Looked up on every call that asks — a pointer value can come back as another kind of memory after a free — which costs
+// well under a microsecond on calls of 60 us and more (N > 8192). The promise of nbody.h / INTEGRATION.md is made for the three kinds
+// of memory the tests pin (hipMalloc, hipHostMalloc, hipMallocManaged); anything this test cannot classify is synchronised the slow way.
 bool arrays_are_device_memory(const void* x, const void* a, const void* v)
 {
     for (const void* p : {x, a, v}) {
@@ -787,7 +798,7 @@ bool arrays_are_device_memory(const void* x, const void* a, const void* v)
             (void)hipGetLastError();   // not known to the runtime (pageable host memory under HMM, ...): not device memory
             return false;
         }
-        if (at.type != hipMemoryTypeDevice || at.isManaged) return false;
+        if (at.type != hipMemoryTypeDevice || at.isManaged || at.allocationFlags != 0) return false;
     }
     return true;
 }

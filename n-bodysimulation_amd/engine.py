@@ -212,9 +212,17 @@ class Context:
     def sync(self) -> None:
         check(self._lib.nbody_ctx_sync(self._h))
 
-    def timing(self, enable: bool) -> None:
-        """Bracket every force launch with hipEvents on the launch stream (bench.py's roofline)."""
-        check(self._lib.nbody_ctx_timing(self._h, 1 if enable else 0))
+    def timing(self, enable: bool, clock: bool = False) -> None:
+        """Bracket every force launch with hipEvents on the launch stream (bench.py's roofline); clock=True adds a clock-stamp
+        launch on either side of the pair (shader cycles and 100-MHz ticks per XCD: clock_read)."""
+        check(self._lib.nbody_ctx_timing(self._h, (2 if clock else 1) if enable else 0))
+
+    def clock_read(self) -> dict:
+        """What the clock stamps around the timed force launches since the last read say: shader cycles per launch, the shader
+        clock held under that load (MHz; overall, slowest and fastest XCD), the launch's duration by the 100-MHz counter."""
+        r = _lib.ClockReport()
+        check(self._lib.nbody_ctx_clock_read(self._h, C.byref(r)))
+        return {k: getattr(r, k) for k, _ in r._fields_}
 
     def timing_read(self):
         """(summed force-kernel ms, launches) since the last read; synchronises the stream."""

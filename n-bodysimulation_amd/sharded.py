@@ -271,11 +271,15 @@ class ShardedSimulation:
         self._check(self._lib.nbody_shard_comm_timing(self._h, 1 if enable else 0))
 
     def comm_report(self) -> dict:
-        """Per-step means: all-gather time, the part of it not hidden behind the own-block pass, exchange time."""
-        k, g, ge, x, xe = C.c_int(), C.c_double(), C.c_double(), C.c_double(), C.c_double()
-        self._check(self._lib.nbody_shard_comm_report(self._h, C.byref(k), C.byref(g), C.byref(ge), C.byref(x), C.byref(xe)))
-        return {"steps": k.value, "all_gather_ms_avg": g.value, "exposed_ms_avg": ge.value, "exchange_ms_avg": x.value,
-                "exchange_exposed_ms_avg": xe.value,
+        """Over the timed steps, mean AND maximum: all-gather time, the part of it not hidden behind the own-block pass, exchange
+        time and its exposed part (a single late collective shows in the maxima, not in the means)."""
+        r = _lib.CommReport()
+        self._check(self._lib.nbody_shard_comm_report_ex(self._h, C.byref(r)))
+        return {"steps": r.steps, "all_gather_ms_avg": r.gather_ms, "exposed_ms_avg": r.gather_exposed_ms, "exchange_ms_avg": r.exchange_ms,
+                "exchange_exposed_ms_avg": r.exchange_exposed_ms,
+                "all_gather_ms_max": r.gather_ms_max, "exposed_ms_max": r.gather_exposed_ms_max, "exchange_ms_max": r.exchange_ms_max,
+                "exchange_exposed_ms_max": r.exchange_exposed_ms_max,
+                "gathers": r.gathers, "exchanges": r.exchanges, "records_kept": r.records_kept,
                 "schedule": {0: "canonical", 1: "onesided", 2: "symmetric"}[self.plan.schedule]}
 
     def set_velocity(self, velocity: np.ndarray) -> None:

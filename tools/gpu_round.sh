@@ -8,7 +8,9 @@
 #   bench     python bench.py --steps 20 --warmup 5                                    (the driver's N = 1 command)
 #   prof      rocprofv3 --kernel-trace --stats of the same bench command (3 repeats, no CPU baseline, no extras)
 #   configs   bench lines + kernel stats of the other BASELINE configs on one GPU (N = 65536, fp64, N = 1048576)
-#   sizes     bench lines at N = 8192 and 65536, and the default bench with --masses random
+#   sizes     ONE box, general pair arithmetic, queued steps: bench lines at N = 4096, 8192, 16384, 32768, 45056, 65536, 131072, 160000, 262144,
+#             1048576 (+ the default bench with --masses random), then tools/sizes_table.py: fraction of peak, decomposition, shader clock per size
+#   pmcn      PMC passes (SQ group, GRBM) of bench.py at the sizes in $PMC_N (default "16384 32768": the two rows furthest below the roofline)
 #   sync      tools/sync_probe (N = 8192 and 16384) + nbody_headless --sync-each-step: what a synchronous simulate() per step costs
 #   rank      ONE rank of configs[3] alone (tools/rank_probe.py under rocprofv3 --stats; G = 8 and G = 1; general and equal-mass path)
 #   local8    nbody_headless --ngpu 8 --transport local --share-devices at N = 1048576 under rocprofv3 --stats (and --ngpu 1)
@@ -16,9 +18,6 @@
 #   pmc       PMC passes (one counter group per run, --kernel-trace only beside --pmc): the bench's general path, its equal-mass path
 #             (--equal-mass auto), and tools/sync_probe at N = 8192 (the two fused kernels); then tools/pmc_summary.py
 #   rehearse  bench.py --gpus 4 --fake-hosts at N = 1048576 (four RCCL ranks on the one GPU), both transports, started WITHOUT a launcher
-#   hunt      the 3-rank one-GPU RCCL rehearsal (bench.py --gpus 3 --fake-hosts, both transports, and the sharded-simulation test) over and over
-#             for up to 15 minutes, each run under a deadline with bench.py's stack dump armed: looks for the ONE stall seen in round 3
-#             (about one in thirty runs, no stack then). Stops at the first run that fails or stalls and keeps its stderr
 #   pkbank    tools/pkbank_mb: does the VGPR bank of a packed instruction's operands change its issue cost?
 #   multirank only the multi-rank files of the GPU suite (tests/test_gpu_sharded.py, tests/test_zz_rccl_rehearsal.py)
 #   contend   three processes stepping the reference's loop while a fourth keeps the GPU full; results compared byte for byte
@@ -67,9 +66,21 @@ for stage in $STAGES; do
     prof prof_n1048576 python3 $REPO/bench.py --no-cpu-baseline --no-equal-mass-extras --repeats 2 --bodies 1048576 --steps 3 --warmup 1; rc=$?
     for f in n65536 f64 n1048576; do stats_head $OUT/prof_$f 3; done ;;
   sizes)
-    timeout -k 10 300 python3 bench.py --bodies 8192 --steps 2000 --warmup 100 --no-cpu-baseline > $OUT/n8192_bench.json 2> $OUT/n8192_bench.err && \
-    timeout -k 10 300 python3 bench.py --bodies 65536 --steps 1000 --warmup 50 --no-cpu-baseline > $OUT/n65536_bench.json 2> $OUT/n65536_bench.err && \
-    timeout -k 10 300 python3 bench.py --masses random --no-cpu-baseline > $OUT/n262144_random_masses_bench.json 2> $OUT/n262144_random_masses_bench.err; rc=$? ;;
+    for spec in 4096:20000:500 8192:10000:500 16384:4000:200 32768:1500:100 45056:1000:50 65536:400:40 131072:100:10 160000:60:6 262144:20:5 1048576:3:1; do
+      IFS=: read n k w <<< "$spec"
+      [ $rc -eq 0 ] || break
+      timeout -k 10 300 python3 bench.py --bodies $n --steps $k --warmup $w --min-seconds 4 --no-cpu-baseline > $OUT/n${n}_bench.json 2> $OUT/n${n}_bench.err; rc=$?
+    done
+    [ $rc -eq 0 ] && { timeout -k 10 300 python3 bench.py --masses random --no-cpu-baseline > $OUT/n262144_random_masses_bench.json 2> $OUT/n262144_random_masses_bench.err; rc=$?; }
+    python3 tools/sizes_table.py $OUT | tee $OUT/sizes_table.md ;;
+  pmcn)
+    for n in ${PMC_N:-16384 32768}; do
+      [ $rc -eq 0 ] || break
+      k=$((400000000 / n / (n / 4096))); [ $k -gt 2000 ] && k=2000; [ $k -lt 3 ] && k=3
+      B="python3 $REPO/bench.py --bodies $n --steps $k --warmup 2 --repeats 1 --no-cpu-baseline --no-equal-mass-extras --no-clock"
+      pmc n${n}_sq1 $SQ1 $B && pmc n${n}_grbm $GRBM $B; rc=$?
+    done
+    python3 tools/pmc_summary.py $OUT $OUT/summary ;;
   sync)
     for n in 8192 16384; do timeout -k 10 120 build/sync_probe $n 3000 > $OUT/sync_probe_n$n.txt 2>&1 || rc=$?; done
     grep -E "simulate\(\) per step|queued: nbody_step" $OUT/sync_probe_n8192.txt $OUT/sync_probe_n16384.txt
@@ -117,16 +128,6 @@ for stage in $STAGES; do
       [ $rc -eq 0 ] || break
       timeout -k 10 500 python bench.py --gpus 4 --fake-hosts --comm $comm --steps 3 --warmup 1 --repeats 3 > $OUT/rehearsal_4ranks_n1048576_$comm.json 2> $OUT/rehearsal_4ranks_n1048576_$comm.err; rc=$?
     done ;;
-  hunt)
-    t0=$SECONDS; k=0
-    while [ $((SECONDS - t0)) -lt 900 ] && [ $rc -eq 0 ]; do
-      k=$((k + 1)); comm=native; [ $((k % 2)) -eq 0 ] && comm=torch
-      NBODY_BENCH_STACKS_AFTER=70 timeout -k 10 100 python bench.py --gpus 3 --fake-hosts --comm $comm --bodies 49152 --steps 2 --warmup 2 --repeats 2 \
-          > $OUT/hunt_$k.json 2> $OUT/hunt_$k.err; rc=$?
-      echo "hunt run $k comm=$comm rc=$rc elapsed=$((SECONDS - t0))s $(python3 -c "import json,sys;d=json.loads([l for l in open('$OUT/hunt_$k.json') if l.startswith('{')][-1]);print('ms/step %.2f ag %.2f ex %.2f'%(d['ms_per_step'],d['config']['comm_rank0']['all_gather_ms_avg'],d['config']['comm_rank0']['exchange_ms_avg']))" 2>/dev/null)" | tee -a $OUT/hunt.txt
-      [ $rc -eq 0 ] && [ $k -gt 1 ] && find "$OUT" -maxdepth 1 -name "hunt_$((k - 1)).*" -delete
-    done
-    [ $rc -eq 0 ] || { echo "== FAILED RUN $k: stderr tail" | tee -a $OUT/hunt.txt; tail -120 $OUT/hunt_$k.err | tee -a $OUT/hunt.txt; } ;;
   contend)
     base="--n 8192 --steps 1500 --init libc --sync-each-step"
     $HEADLESS $base --dump $OUT/alone | tail -1 > $OUT/alone.json

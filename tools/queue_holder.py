@@ -1,5 +1,5 @@
 """Holds a GPU context with several busy-once streams, like a test runner that has already used the GPU, then sleeps.
-Used by tools/gpu_r04a.sh to see what a bystander process does to ranks that share the GPU (hardware queue slots)."""
+Used in round 4's priority probe (profiles/r04a_rehearsal_priority_probe.txt; that round's visit script is gone) to see what a bystander process does to ranks that share the GPU (hardware queue slots)."""
 import os
 import sys
 import time
