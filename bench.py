@@ -380,6 +380,8 @@ def parse_args():
     ap.add_argument("--sym-bpl", type=int, default=0)
     ap.add_argument("--workspace-limit-mib", type=float, default=0.0, help="nbody_ctx_set_workspace_limit: cap on the context's partial-sum workspace "
                     "(0 = automatic); config.launch says what the step does under it")
+    ap.add_argument("--inplace-sums", default="auto", choices=["auto", "on", "off"], help="nbody_ctx_set_inplace_sums: block pairs with the partial sums added in "
+                    "place (no slab workspace). auto: only where the slab workspace does not fit its cap; on: wherever unit runs / block pairs would run; off: never")
     ap.add_argument("--masses", default="init", choices=["init", "random"], help="init: as the initial conditions give them (Plummer: every body 1/N, "
                     "which the symmetric kernels' equal-mass path picks up; cube: the reference's random masses); random: Plummer positions "
                     "with masses drawn uniformly over a decade, as the reference's fill_with_random4 does, total 1 - the general path")
@@ -607,6 +609,8 @@ def build_simulation(R) -> None:
         R.ctx = R.sim.ctx
         if args.workspace_limit_mib > 0:
             R.ctx.set_workspace_limit(int(args.workspace_limit_mib * 2 ** 20))
+        if args.inplace_sums != "auto":
+            R.ctx.set_inplace_sums(1 if args.inplace_sums == "on" else 0)
         if args.sym_waves or args.sym_bpl:
             R.ctx.set_symmetric_shape(args.sym_waves, args.sym_bpl)
             R.ctx.reserve(n)
@@ -931,6 +935,7 @@ def roofline_block(R, T, em):
                   ("nbk::step_fused (fp32 packed, one-sided, force + integrate in one launch)" if info.get("fused") else
                    "nbk::force_sym_bal (fp32 packed, each unordered pair once, balanced runs)" if info.get("balanced") else
                    "nbk::force_sym_run (fp32 packed, each unordered pair once, unit runs)" if info.get("runs") else
+                   "nbk::force_sym_ticket (fp32 packed, each unordered pair once, block sums added in place: no slab workspace)" if info.get("ticket") else
                    "nbk::force_sym / force_sym_square (fp32 packed, each unordered pair once)" if symmetric else "nbk::force_lds (fp32 packed, one-sided)"),
         "kernel_ms_per_step": kernel_s_step * 1e3,
         "kernel_time_source": ("HIP events around every force launch of the timed repeats" if inline else

@@ -35,10 +35,11 @@
  *     utils.h       nbody_fill_with_random4  nbody_fill_with_zeroes4  nbody_fill_with_zeroes3  nbody_random_float  nbody_print_device_prop
  *     validation.h  nbody_verify_still_bodies  nbody_verify_equality4  nbody_verify_equality3
  *     around it     nbody_simulate_prepare  nbody_default_ctx  nbody_simulate_host_legacy (the older snapshot's host-pointer boundary)
- *   EXTENSIONS — no reference counterpart; a caller of the boundary never needs them (65):
+ *   EXTENSIONS — no reference counterpart; a caller of the boundary never needs them (67):
  *     contexts and knobs      nbody_ctx_create  nbody_ctx_destroy  nbody_ctx_set_params  nbody_ctx_set_kernel  nbody_ctx_set_symmetric_shape
  *                             nbody_ctx_set_symmetric_runs  nbody_ctx_set_fused  nbody_ctx_set_fused_inplace  nbody_ctx_fused_inplace_stats
- *                             nbody_ctx_set_equal_mass  nbody_ctx_equal_mass_verdict  nbody_ctx_set_workspace_limit  nbody_ctx_set_stream
+ *                             nbody_ctx_set_equal_mass  nbody_ctx_equal_mass_verdict  nbody_ctx_set_workspace_limit  nbody_ctx_set_inplace_sums
+ *                             nbody_ctx_set_stream
  *                             nbody_ctx_set_graph  nbody_ctx_reserve  nbody_ctx_sync  nbody_ctx_get  nbody_device_count
  *     queued stepping, pieces nbody_step  nbody_step_f64  nbody_accel_range  nbody_accel_square_part  nbody_accel_wrapped  nbody_accel_cross
  *                             nbody_integrate_range
@@ -51,6 +52,7 @@
  *                             nbody_comm_rccl_unique_id  nbody_comm_rccl_create  nbody_comm_rccl_destroy  nbody_comm_local_group_create
  *                             nbody_comm_local_group_destroy  nbody_comm_local_create  nbody_comm_local_destroy  nbody_comm_local_abort
  *     what would be launched  nbody_version  nbody_plan  nbody_plan_symmetric  nbody_plan_fused  nbody_plan_symmetric_occupancy
+ *                             nbody_plan_ticket_task
  *                             nbody_ctx_launch_info  nbody_ctx_step_info  nbody_ctx_step_info_f64  nbody_ctx_square_info
  *     seeded initial data     nbody_fill_seeded
  */
@@ -218,13 +220,27 @@ int nbody_ctx_set_equal_mass(nbody_ctx* ctx, int mode);
 int nbody_ctx_equal_mass_verdict(nbody_ctx* ctx, int* scanned, int* uniform, float* mass);
 
 /* The symmetric kernels keep one slab of partial sums per block of bodies (nb x n x 16 B: 412 MiB at N = 262144, 6.4 GiB at
- * N = 1048576, growing as N^2/B). The launch-shape choice only uses a symmetric decomposition whose workspace fits a cap:
+ * N = 1048576, growing as N^2/B). The launch-shape choice only uses a slab decomposition whose workspace fits a cap:
  * min(96 GiB, half of the device memory that is free, `bytes` if non-zero); beyond it — or when the allocation itself fails —
- * the step falls back to the next smaller footprint and finally to the one-sided kernel (<= 64 slabs, about 30 % slower at
- * large N) instead of returning an error. nbody_accel_cross cuts its source run into pieces instead. bytes = 0: automatic.
- * fail_above != 0 is a TEST hook: the shape choice ignores `bytes`, and every workspace allocation larger than `bytes` fails as
- * if the device were out of memory (exercises the fallback path without exhausting a 288 GB device). */
+ * a whole step keeps the symmetric arithmetic and adds the block sums IN PLACE instead (nbody_ctx_set_inplace_sums below: no
+ * workspace at all); nbody_accel_range on a square block falls back to the next smaller footprint and finally to the one-sided
+ * kernel (<= 64 slabs, about 30 % slower at large N); nbody_accel_cross cuts its source run into pieces. Never an error.
+ * bytes = 0: automatic. fail_above != 0 is a TEST hook: the shape choice ignores `bytes`, and every workspace allocation larger
+ * than `bytes` fails as if the device were out of memory (exercises the fallback path without exhausting a 288 GB device). */
 int nbody_ctx_set_workspace_limit(nbody_ctx* ctx, size_t bytes, int fail_above);
+
+/* Block pairs with the partial sums added IN PLACE (nbk::force_sym_ticket): the same pair arithmetic and block shapes as the slab
+ * kernel, but every task ADDS its two block sums into one of a few accumulation lanes per body (8 x 16 n bytes where the cap allows:
+ * a few per cent of the slab footprint; fewer under a tight cap; with one lane the sums go straight into d_accelerations and there is
+ * no workspace at all), in an order fixed per block and lane by a ticket (the same bits on every run), through agent-scope accesses;
+ * the integrate adds the lanes in index order. The reference's
+ * analogue is its shared-memory guard that rejects large N outright (kernel.cu:639-641); here N has no workspace cliff.
+ * mode -1 (default): whole steps whose slab workspace does not fit the cap above; 1: every whole step FAST / SYMMETRIC would run as
+ * unit runs or block pairs (from 12288 bodies; balanced runs and the fused small-N step keep their own sizes); 0: never (the older
+ * fallback: one-sided kernel). The sums differ from the slab kernel's by rounding only (another, equally fixed order of the same
+ * nb block sums per body). A workgroup that waited more than 10 s for its turn (never on a healthy run) raises an error that the next
+ * nbody_step / nbody_ctx_sync returns. */
+int nbody_ctx_set_inplace_sums(nbody_ctx* ctx, int mode);
 
 /* Launch on this HIP stream (a hipStream_t passed as void*; NULL = the context's own stream). */
 int nbody_ctx_set_stream(nbody_ctx* ctx, void* hip_stream);
@@ -527,7 +543,8 @@ int nbody_ctx_launch_info(nbody_ctx* ctx, int n_targets, int n_sources, int* jsp
                           int* lds_bytes);
 
 /* What nbody_step() does for n bodies: symmetric = 1 when the symmetric kernel runs on block pairs, 2 when it runs in
- * runs of chunk units, 3 in balanced runs of rotation steps (slabs = records per inbox), 0 for the one-sided kernel, -1 for the fused
+ * runs of chunk units, 3 in balanced runs of rotation steps (slabs = records per inbox), 4 on block pairs with the sums added in
+ * place (slabs = accumulation lanes, 0 when the sums go straight into the acceleration array: nbody_ctx_set_inplace_sums), 0 for the one-sided kernel, -1 for the fused
  * small-N step (one-sided arithmetic, force + integrate in one launch: slabs = 0, block_bodies = targets per workgroup); block_bodies = bodies
  * per block (symmetric) or per workgroup (one-sided); slabs = partial-sum slabs the integrate adds;
  * workgroups = grid size; evaluated_pairs = pair evaluations per step (n*n one-sided; about n*n/2 plus
@@ -567,6 +584,12 @@ int nbody_plan_fused(int n, int num_cu, int* out_targets_per_wave, int* out_wave
  * lane (2 at 10, 3 at 8, 5 at 4, 8 at 2): a property of the compiled kernels' register allocation, checked against the
  * compiler's own resource report by tests/test_build_resources.py. 0 for an unsupported count. */
 int nbody_plan_symmetric_occupancy(int bodies_per_lane);
+
+/* The in-place block-pair kernel's task list without a device (host tests): task t of a launch over nb blocks evaluates the block
+ * pair (i, j) — anti-diagonal by anti-diagonal, then the nb diagonal blocks — and its sums are contribution number seq_i of block i
+ * and seq_j of block j (-1 for a diagonal task, which has one sum): every block receives contributions 0 .. nb-1 exactly once, and a
+ * contribution's predecessor always belongs to an earlier task. */
+int nbody_plan_ticket_task(int nb, int task, int* out_i, int* out_j, int* out_seq_i, int* out_seq_j);
 
 #ifdef __cplusplus
 }

@@ -106,6 +106,8 @@ _SIGNATURES = {
     "nbody_ctx_set_equal_mass": (C.c_int, [_p, C.c_int]),
     "nbody_ctx_equal_mass_verdict": (C.c_int, [_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "nbody_ctx_set_workspace_limit": (C.c_int, [_p, C.c_size_t, C.c_int]),
+    "nbody_ctx_set_inplace_sums": (C.c_int, [_p, C.c_int]),
+    "nbody_plan_ticket_task": (C.c_int, [C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4),
     "nbody_ctx_set_stream": (C.c_int, [_p, _p]),
     "nbody_ctx_reserve": (C.c_int, [_p, C.c_int]),
     "nbody_ctx_set_graph": (C.c_int, [_p, C.c_int]),

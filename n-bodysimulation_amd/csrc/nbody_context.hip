@@ -84,6 +84,47 @@ int ensure_fsync(nbody_ctx* c, size_t nwaves)
     return NBODY_OK;
 }
 
+// the ticket kernel's per-block words (zeroed once: every launch leaves them zero) and its host-mapped error word
+int ensure_tickets(nbody_ctx* c)
+{
+    if (!c->terr) {
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&c->terr), 64, hipHostMallocMapped | hipHostMallocCoherent);
+        if (e == hipSuccess) {
+            c->terr[0] = 0;
+            e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->terr_dev), c->terr, 0);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            if (c->terr) (void)hipHostFree(c->terr);
+            c->terr = c->terr_dev = nullptr;
+            return fail(NBODY_ERR_NOMEM, "cannot allocate the ticket kernel's host-mapped word: %s", hipGetErrorString(e));
+        }
+    }
+    if (c->tickets) return NBODY_OK;
+    static_assert(nbk::kTicketWords == kSymMaxSlabs * nbk::kTicketMaxLanes, "one ticket per block and lane");
+    const size_t bytes = (size_t)(nbk::kTicketWords + 1) * sizeof(unsigned);   // + the abort word
+    const hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->tickets), bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        c->tickets = nullptr;
+        return fail(NBODY_ERR_NOMEM, "cannot allocate the ticket words: %s", hipGetErrorString(e));
+    }
+    HIP_TRY(hipMemsetAsync(c->tickets, 0, bytes, c->stream));
+    return NBODY_OK;
+}
+
+// A ticket wait that timed out (never on a healthy run) leaves sums that are not to be trusted and tickets that are not zero: the
+// next call that looks says so ONCE, after putting the tickets back (so that stepping can go on from whatever state the caller restores).
+int ticket_error(nbody_ctx* c)
+{
+    if (!c->terr || !*static_cast<volatile unsigned*>(c->terr)) return NBODY_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *static_cast<volatile unsigned*>(c->terr) = 0;
+    if (c->tickets) HIP_TRY(hipMemsetAsync(c->tickets, 0, (size_t)(nbk::kTicketWords + 1) * sizeof(unsigned), c->stream));
+    return fail(NBODY_ERR_HIP, "a workgroup of the in-place block-pair kernel waited more than 10 s for its turn to add (a predecessor did not finish): "
+                               "the accelerations of that step are incomplete");
+}
+
 // Recomputes the effective workspace cap from what the device has free right now (the context's own workspaces count as
 // available: they are released before a larger one is allocated). Needs the context's device to be current.
 void refresh_ws_cap(nbody_ctx* c)
@@ -168,7 +209,9 @@ static int ensure_cstamp(nbody_ctx* c)
     if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->cdelta_dev), c->cdelta, 0);
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        if (c->cdelta) (void)hipHostFree(c->cdelta);
+        if (c->tickets) (void)hipFree(c->tickets);
+    if (c->terr) (void)hipHostFree(c->terr);
+    if (c->cdelta) (void)hipHostFree(c->cdelta);
         c->cdelta = c->cdelta_dev = nullptr;
         return fail(NBODY_ERR_NOMEM, "cannot allocate the clock-stamp records (%zu bytes): %s", bytes, hipGetErrorString(e));
     }
@@ -293,6 +336,8 @@ int nbody_ctx_destroy(nbody_ctx* c)
     if (c->xalt) (void)hipFree(c->xalt);
     if (c->fsync) (void)hipFree(c->fsync);
     if (c->fhost) (void)hipHostFree(c->fhost);
+    if (c->tickets) (void)hipFree(c->tickets);
+    if (c->terr) (void)hipHostFree(c->terr);
     if (c->cdelta) (void)hipHostFree(c->cdelta);
     if (c->cscratch) (void)hipFree(c->cscratch);
     if (c->eqm) (void)hipFree(c->eqm);
@@ -444,6 +489,14 @@ int nbody_ctx_set_workspace_limit(nbody_ctx* c, size_t bytes, int fail_above)
     return NBODY_OK;
 }
 
+int nbody_ctx_set_inplace_sums(nbody_ctx* c, int mode)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (mode < -1 || mode > 1) return fail(NBODY_ERR_CONFIG, "in-place sums mode must be -1 (auto), 0 (never) or 1 (always)");
+    c->inplace_sums = mode;
+    return NBODY_OK;
+}
+
 int nbody_ctx_set_stream(nbody_ctx* c, void* hip_stream)
 {
     if (int rc = check_ctx(c)) return rc;
@@ -586,7 +639,7 @@ int nbody_ctx_sync(nbody_ctx* c)
     // (a host_signal launch + a spin here, as nbody_simulate does, measured 1 us per call at best — 34.7 -> 33.8 us for a step + sync at
     //  N = 8192 — and nothing for long queues: not adopted, the plain synchronisation stays)
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return NBODY_OK;
+    return ticket_error(c);
 }
 
 int nbody_ctx_get(nbody_ctx* c, int* device, int* kernel, void** hip_stream)

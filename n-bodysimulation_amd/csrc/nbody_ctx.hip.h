@@ -75,6 +75,12 @@ struct nbody_ctx {
     int eq_last_slot = 0;      // slot the last scan wrote
     int eq_mode = -1;          // equal-mass path of the symmetric kernels where the device-side scan finds one common mass: -1 launches of
                                // kEqAutoMinBodies bodies or more, 1 of kEqMinBodies or more, 0 never
+    // block pairs with the sums added IN PLACE (nbk::force_sym_ticket: no slab workspace)
+    int inplace_sums = -1;     // -1 auto: where the slab workspace of the block-pair kernel does not fit the cap (instead of the one-sided kernel);
+                               //  0 never; 1 wherever FAST / SYMMETRIC would run unit runs or block pairs
+    unsigned* tickets = nullptr;     // device: one word per block (kSymMaxSlabs of them), zero between launches
+    unsigned* terr = nullptr;        // host-mapped: a ticket wait timed out (the launch's sums are not to be trusted)
+    unsigned* terr_dev = nullptr;
     void* xslabs = nullptr;    // workspace of nbody_accel_cross (its own, so that a square evaluation issued in parts
     size_t xslab_bytes = 0;    // around cross launches keeps its partial sums)
     bool legacy_eps = false;     // strict kernel evaluates `+ EPS2` as the older snapshot does
@@ -190,7 +196,9 @@ int simulate_prepare_locked(nbody_ctx* c, const nbody_float4* d_bodies, int n);
 Shape resolve_shape(const nbody_ctx* c, int n_targets, int n_sources);
 int sym_waves_per_simd(int bpl);
 double sym_cost(int W, int bpl, long tasks, double slab_bytes, int num_cu);
-bool sym_resolve(const nbody_ctx* c, int n, SymShape* out);
+bool sym_resolve(const nbody_ctx* c, int n, SymShape* out, bool ignore_cap = false);
+bool ticket_wanted(const nbody_ctx* c, int n, SymShape* out);
+int ticket_lanes(const nbody_ctx* c, int n, int nb);
 bool sym_resolve_cross(const nbody_ctx* c, int ni, int nj, SymShape* out, int* nbj, bool* hopeless = nullptr);
 bool run_resolve(const nbody_ctx* c, int n, RunShape* out, double* cost_out);
 bool run_wanted(const nbody_ctx* c, int n, RunShape* out);
@@ -206,6 +214,8 @@ int check_ctx(const nbody_ctx* c);
 int time_mark(nbody_ctx* c);
 int ensure_xalt(nbody_ctx* c, int n);
 int ensure_fsync(nbody_ctx* c, size_t nwaves);
+int ensure_tickets(nbody_ctx* c);
+int ticket_error(nbody_ctx* c);   // NBODY_OK, or the error a timed-out ticket wait of an earlier launch left behind (and the tickets reset)
 void refresh_ws_cap(nbody_ctx* c);
 int grow_workspace(nbody_ctx* c, void** buf, size_t* have, size_t bytes);
 int ensure_xslabs(nbody_ctx* c, size_t bytes);

@@ -365,6 +365,13 @@ struct SymParamsT {
     S eps2;
     const MassInfo* eqm;  // mass_scan's verdict on this launch's ranges (nullptr: general path)
     unsigned int eq_gen;  // this launch's generation
+    // force_sym_ticket only (sums added in place, no slabs): acc_lanes accumulation arrays of the range's bodies, acc_stride elements
+    // apart (ONE lane = the acceleration array itself); one ticket word per (block, lane), zero between launches, the abort word
+    // behind them; the host-mapped error word
+    V4* acc;
+    unsigned* tickets;
+    unsigned* err;
+    int acc_lanes, acc_stride;
 };
 using SymParams = SymParamsT<float4, float>;
 using SymParamsF64 = SymParamsT<double4, double>;
@@ -613,7 +620,134 @@ __device__ __forceinline__ int sym_row_offset(int I, int nb) { return (int)(((lo
 // is WRITTEN, not only to what it computes: a first version (stores through lambdas, the equal-mass dispatch in a helper) had the same VALU
 // count and ran 2 % slower on the general path. Re-measure (`tools/gpu_round.sh <tag> symab`, table by
 // tools/symbench_ab_table.py) after touching it.
-enum SymCase : int { kSymGeneral = 0, kSymSquare = 1, kSymRect = 2 };
+//   kSymTicket   the SQUARE case with the partial sums added IN PLACE (no slab workspace): see force_sym_ticket below.
+enum SymCase : int { kSymGeneral = 0, kSymSquare = 1, kSymRect = 2, kSymTicket = 3 };
+
+// ---- sums in place: the TICKET protocol of force_sym_ticket ----------------------------------------------------------------------
+// The slab layout costs nb x 16 N bytes (one partial sum per body per block: 412 MiB at N = 262144, 6.4 GiB at 1 M, beyond any cap
+// near 4 M). Here every task adds its two block sums straight into the acceleration array instead, and the ORDER in which the nb
+// contributions of a block are added is fixed by a ticket per block, so the result is the same bits on every run:
+//   * tasks are listed ANTI-DIAGONAL by anti-diagonal — d = 1 .. nb-1, within it (I, I + d) by I — and then the nb diagonal blocks; a
+//     block meets at most two tasks per anti-diagonal, so the ~500 tasks in flight at any time touch a block about ten times, spread
+//     over the whole round (the row-major list of the slab kernels would put a row's hundred tasks — all contributors to ONE block —
+//     side by side);
+//   * contribution number s of block K (counted along that list; closed forms below) goes to accumulation LANE s mod L (L = 1, 2, 4 or 8
+//     arrays of N sums; the integrate adds the lanes in index order): the ~ten contributions a block receives per round of resident
+//     tasks — which all finish within microseconds of each other — then queue up two deep instead of ten deep. It waits until
+//     tickets[K][lane] == s / L, adds (a lane's first contribution stores), drains its stores (s_waitcnt vmcnt(0) in every wave, then
+//     the workgroup barrier), and hands the ticket on; a lane's last contribution leaves its ticket at zero for the next launch. With
+//     L = 1 the one lane is the acceleration array itself: no workspace at all;
+//   * data moves through agent-scope atomics (global_load/store_dwordx2 sc1): the eight XCDs' L2s are not coherent for ordinary
+//     accesses, and an agent-scope load is defined to see an agent-scope store that completed before it was issued.
+// A waiter only ever waits for a task EARLIER in the list. Workgroups of a grid start in index order, so the earliest unfinished task
+// is always resident and never waits: no deadlock; and should a wait exceed ten seconds all the same (a stopped predecessor), the
+// waiter raises the host-mapped error word and goes on — a wrong, flagged result instead of a hung GPU (the host checks the word at
+// its next synchronisation and returns an error).
+constexpr unsigned long long kTicketTimeoutTicks = 1000000000ull;   // 10 s of the 100-MHz counter
+
+__device__ __forceinline__ float4 load_f4_agent(const float4* src)
+{
+    unsigned long long* const q = reinterpret_cast<unsigned long long*>(const_cast<float4*>(src));
+    const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float4(__builtin_bit_cast(float, (unsigned)lo), __builtin_bit_cast(float, (unsigned)(lo >> 32)),
+                       __builtin_bit_cast(float, (unsigned)hi), __builtin_bit_cast(float, (unsigned)(hi >> 32)));
+}
+
+__device__ __forceinline__ void store_f4_agent(float4* dst, const float4 v)
+{
+    unsigned long long* const q = reinterpret_cast<unsigned long long*>(dst);
+    const unsigned long long lo = (unsigned long long)__builtin_bit_cast(unsigned, v.x) | ((unsigned long long)__builtin_bit_cast(unsigned, v.y) << 32);
+    const unsigned long long hi = (unsigned long long)__builtin_bit_cast(unsigned, v.z) | ((unsigned long long)__builtin_bit_cast(unsigned, v.w) << 32);
+    __hip_atomic_store(q, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ONE thread: returns once *tk == want. `abort` is the word behind the last ticket: set by the first waiter that gives up, it lets every
+// later wait of the launch fall through at once (the launch ends within seconds instead of one time-out per waiter).
+__device__ __forceinline__ void ticket_spin(unsigned* const tk, const unsigned want, unsigned* const abort, unsigned* const err)
+{
+    if (__hip_atomic_load(tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        __builtin_amdgcn_s_sleep(2);
+        if (__hip_atomic_load(tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want) return;
+        if (__hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > kTicketTimeoutTicks) {   // never on a healthy run: flag it and go on
+            __hip_atomic_store(abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+    }
+}
+
+// all threads of the workgroup: returns once the turn has come (thread 0 looks, the barrier tells the others)
+__device__ __forceinline__ void ticket_wait(unsigned* const tk, const unsigned want, unsigned* const abort, unsigned* const err)
+{
+    if (threadIdx.x == 0) ticket_spin(tk, want, abort, err);
+    __syncthreads();
+}
+
+// every wave has drained its stores, then ONE thread hands the ticket on
+__device__ __forceinline__ void ticket_pass(unsigned* const tk, const unsigned next)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the barrier alone waits for no store (hipcc emits lgkmcnt(0) in front of s_barrier)
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(tk, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the I-side sums of a task (registers) -> added into their lane of acc at block I; contribution number `seq` of the nb of that block.
+// (Measured: awaiting both turns of a task first and adding both sums in one go — one round trip instead of two — is 0.3 % SLOWER at
+// N = 262144, and 1.5 % slower on the equal-mass path, than the two additions one after the other: profiles/r06b_inplace_ab.txt.)
+template <class M, bool EQ>
+__device__ __forceinline__ void sym_add_i(M& t, const SymParams& p, const int ibase, const int I, const unsigned seq, const float m0)
+{
+    if (EQ) t.scale(m0);
+    const unsigned L = (unsigned)p.acc_lanes, lane = seq & (L - 1u), turn = seq / L;   // L is a power of two
+    unsigned* const tk = p.tickets + (unsigned)I * L + lane;
+    float4* const acc = p.acc + (size_t)lane * p.acc_stride;
+    ticket_wait(tk, turn, p.tickets + kTicketWords, p.err);
+#pragma unroll
+    for (int k = 0; k < M::BPL; ++k) {
+        const int i = ibase + k * 64;
+        if (i < p.ni) {
+            float4 v = t.acc(k);
+            v.w = 0.0f;
+            if (turn) {   // (a lane's first contribution stores: the lanes need no clearing)
+                const float4 o = load_f4_agent(acc + i);
+                v.x += o.x; v.y += o.y; v.z += o.z;
+            }
+            store_f4_agent(acc + i, v);
+        }
+    }
+    ticket_pass(tk, seq + L >= (unsigned)p.nbi ? 0u : turn + 1u);   // the lane's last contribution of the nb: back to zero
+}
+
+// the J-side sums of a task (LDS) -> added into their lane of acc at block J
+template <class M, int W, bool EQ>
+__device__ __forceinline__ void sym_add_j(const float4* const sh, const SymParams& p, const int J, const unsigned seq, const float m0)
+{
+    constexpr int B = 64 * W * M::BPL;
+    const unsigned L = (unsigned)p.acc_lanes, lane = seq & (L - 1u), turn = seq / L;
+    unsigned* const tk = p.tickets + (unsigned)J * L + lane;
+    float4* const acc = p.acc + (size_t)lane * p.acc_stride;
+    ticket_wait(tk, turn, p.tickets + kTicketWords, p.err);
+#pragma unroll
+    for (int e = threadIdx.x; e < B; e += 64 * W) {
+        const int j = J * B + e;
+        if (j < p.ni) {
+            float4 v = sh[e];
+            if (EQ) { v.x *= m0; v.y *= m0; v.z *= m0; }
+            v.w = 0.0f;
+            if (turn) {
+                const float4 o = load_f4_agent(acc + j);
+                v.x += o.x; v.y += o.y; v.z += o.z;
+            }
+            store_f4_agent(acc + j, v);
+        }
+    }
+    ticket_pass(tk, seq + L >= (unsigned)p.nbi ? 0u : turn + 1u);
+}
 
 // the I-side sums of a task (registers of the stationary bodies) -> slab J of the I range
 template <class M, bool EQ>
@@ -662,6 +796,7 @@ __device__ __forceinline__ void force_sym_tile(const SymParamsT<typename M::V4, 
     const int task = p.task0 + (int)blockIdx.x;
     int I, J;
     bool diag = false;
+    constexpr bool kSq = CASE == kSymSquare || CASE == kSymTicket;   // one range against itself, nothing else compiled in
     bool rect = CASE == kSymRect;
     if constexpr (CASE == kSymGeneral) rect = p.rect;
     if (rect) {
@@ -681,12 +816,17 @@ __device__ __forceinline__ void force_sym_tile(const SymParamsT<typename M::V4, 
             while (I < nb - 2 && sym_row_offset(I + 1, nb) <= task) ++I;
             while (I > 0 && sym_row_offset(I, nb) > task) --I;
             J = I + 1 + (task - sym_row_offset(I, nb));
+            if constexpr (CASE == kSymTicket) {   // the same list read anti-diagonal by anti-diagonal: row r holds d = r + 1, entry c is (c, c + d)
+                const int d = I + 1, c0 = J - I - 1;
+                I = c0;
+                J = c0 + d;
+            }
         }
     }
 
     // a body past the end of its range adds exactly +-0 to every real body (pad4), and what it collects itself is never stored
     const V4* const xi = p.x + p.i0;
-    const int nj = CASE == kSymSquare ? p.ni : p.nj;
+    const int nj = kSq ? p.ni : p.nj;
     M t;
     t.set_eps2(p.eps2);
     const int ibase = I * B + w * (64 * BPL) + lane;  // index within the I range
@@ -703,7 +843,7 @@ __device__ __forceinline__ void force_sym_tile(const SymParamsT<typename M::V4, 
 
     auto fetch = [&](int c) {
         const int j = jbase + c * 64;
-        if constexpr (CASE == kSymSquare) {
+        if constexpr (kSq) {
             return j < p.ni ? xi[j] : pad4<V4, EQ>();
         } else {
             int ja = p.j0 + j;
@@ -743,7 +883,13 @@ __device__ __forceinline__ void force_sym_tile(const SymParamsT<typename M::V4, 
         c = cn;
     }
     // (the order of the two stores is part of what was measured per geometry: kept)
-    if constexpr (CASE == kSymGeneral) {
+    if constexpr (CASE == kSymTicket) {
+        // contribution numbers along the anti-diagonal list (tests/test_abi.py checks the closed forms against a walk of the list)
+        const int nb = p.nbi, d = J - I;
+        const unsigned seq_i = diag ? (unsigned)(nb - 1) : (unsigned)((d - 1) + (d < I ? d : I));
+        sym_add_i<M, EQ>(t, p, ibase, I, seq_i, m0);
+        if (!diag) sym_add_j<M, W, EQ>(sh, p, J, (unsigned)((d - 1 < nb - 1 - J ? d - 1 : nb - 1 - J) + (d - 1)), m0);
+    } else if constexpr (CASE == kSymGeneral) {
         sym_store_i<M, EQ>(t, p, ibase, J, m0);
         if (!diag) sym_store_j<M, W, EQ>(sh, p, I, J, nj, m0);
     } else {
@@ -781,6 +927,13 @@ template <class M, int W>
 __global__ void __launch_bounds__(64 * W, 1) force_sym_rect(const SymParamsT<typename M::V4, typename M::S> p)
 {
     NBK_SYM_KERNEL_BODY(kSymRect);
+}
+
+// the square case with the sums added in place (fp32 only): p.acc / p.tickets / p.err instead of slabs
+template <class M, int W>
+__global__ void __launch_bounds__(64 * W, 1) force_sym_ticket(const SymParams p)
+{
+    NBK_SYM_KERNEL_BODY(kSymTicket);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -139,6 +139,9 @@ struct ClockDelta {
 constexpr int kClockBeginWgs = 16;   // workgroups of the stamp in front: consecutive workgroup ids go to consecutive XCDs, two CUs each
 constexpr int kClockEndWgs = 256;    // workgroups of the stamp behind: lands on every CU of an otherwise idle chip, finds its partner by CU
 
+constexpr int kTicketMaxLanes = 8;    // nbk::force_sym_ticket: accumulation lanes per body at most
+constexpr int kTicketWords = 2048 * kTicketMaxLanes;   // one ticket per (block, lane): nbi::kSymMaxSlabs blocks; the word behind them is the launch's abort flag
+
 enum FusedSync : int { kFusedReaders = 0, kFusedFinished = 1, kFusedFallbacksTotal = 2, kFusedSyncWords = 4 };
 
 }  // namespace nbk

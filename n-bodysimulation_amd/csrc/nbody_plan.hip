@@ -94,8 +94,9 @@ double sym_cost(int W, int bpl, long tasks, double slab_bytes, int num_cu)
     return B * step * deep + slab_bytes / 4.7e12 * 2.26e9;                   // slab sum at 4.7 TB/s, 2.26 GHz
 }
 
-bool sym_resolve(const nbody_ctx* c, int n, SymShape* out)
+bool sym_resolve(const nbody_ctx* c, int n, SymShape* out, bool ignore_cap)
 {
+    const size_t cap = ignore_cap ? ~(size_t)0 : c->ws_cap;   // (the ticket kernel keeps no slabs: same shapes, no footprint)
     int pick = -1;
     double best = 0.0;
     int rw, rb;
@@ -105,8 +106,8 @@ bool sym_resolve(const nbody_ctx* c, int n, SymShape* out)
         const long B = 64L * kSymCand[k][0] * kSymCand[k][1];
         const long nb = (n + B - 1) / B;
         if (nb < 2 && pick >= 0) continue;
-        if (nb > kSymMaxSlabs || (size_t)nb * (size_t)n * sizeof(float4) > c->ws_cap) continue;
-        const double cost = sym_cost(kSymCand[k][0], kSymCand[k][1], nb * (nb + 1) / 2, (double)nb * n * sizeof(float4), c->num_cu);
+        if (nb > kSymMaxSlabs || (size_t)nb * (size_t)n * sizeof(float4) > cap) continue;
+        const double cost = sym_cost(kSymCand[k][0], kSymCand[k][1], nb * (nb + 1) / 2, ignore_cap ? 0.0 : (double)nb * n * sizeof(float4), c->num_cu);
         if (pick < 0 || cost < best) { pick = k; best = cost; }
     }
     if (pick < 0) return false;
@@ -117,7 +118,42 @@ bool sym_resolve(const nbody_ctx* c, int n, SymShape* out)
     y.nb = (n + y.block - 1) / y.block;
     y.grid = y.nb * (y.nb - 1) / 2 + y.nb;
     if (y.nb < 2 || y.nb > kSymMaxSlabs) return false;
-    if ((size_t)y.nb * (size_t)n * sizeof(float4) > c->ws_cap) return false;
+    if ((size_t)y.nb * (size_t)n * sizeof(float4) > cap) return false;
+    *out = y;
+    return true;
+}
+
+// How many accumulation lanes the in-place kernel gets for n bodies in nb blocks: 8 where they fit the workspace cap (8 x 16 n bytes: a
+// few per cent of the slab kernel's nb x 16 n), fewer under a tight cap, ONE — the acceleration array itself, no workspace — as the last
+// resort; never more lanes than half the blocks (every lane of every block must receive a contribution).
+int ticket_lanes(const nbody_ctx* c, int n, int nb)
+{
+    int lanes = nbk::kTicketMaxLanes;
+    while (lanes > 1 && ((size_t)lanes * (size_t)n * sizeof(float4) > c->ws_cap || lanes * 2 > nb)) lanes /= 2;
+    return lanes;
+}
+
+// Does a square problem of n bodies go to the block-pair kernel with the sums added IN PLACE (nbk::force_sym_ticket)? Only shapes built
+// for it: four waves x ten bodies per lane (the default large-N block) and one wave x ten (finer tasks for mid sizes).
+bool ticket_wanted(const nbody_ctx* c, int n, SymShape* out)
+{
+    if (c->inplace_sums == 0) return false;
+    if (!(c->kernel == NBODY_KERNEL_SYMMETRIC || (c->kernel == NBODY_KERNEL_FAST && n >= kSymMinAuto))) return false;
+    if (c->sym_runs == 2) return false;                          // balanced runs were asked for explicitly
+    SymShape y{};
+    if (c->inplace_sums < 0 && sym_resolve(c, n, &y)) return false;   // auto: the slab kernel wherever its workspace fits
+    // Two shapes are built: four waves x ten bodies per lane (2560-body blocks: a task of about a millisecond, its two additions a per
+    // cent of it) where that still makes a few thousand tasks, one wave x ten (640-body blocks) below. (The slab kernel's cost estimate
+    // does not know the per-task price of the additions and would always pick the finer shape.)
+    nbody_ctx tmp = *c;
+    tmp.sym_waves = n >= kRunsMaxAuto ? 4 : 1;
+    tmp.sym_bpl = 10;
+    {
+        int rw, rb;
+        fp32_shape_request(c, &rw, &rb);
+        if ((rw == 4 || rw == 1) && (rb == 0 || rb == 10)) tmp.sym_waves = rw;   // an explicit request for a built shape is honoured
+    }
+    if (!sym_resolve(&tmp, n, &y, true)) return false;
     *out = y;
     return true;
 }
@@ -428,6 +464,14 @@ int nbody_ctx_step_info(nbody_ctx* c, int n, int* symmetric, int* block_bodies, 
         if (evaluated_pairs) *evaluated_pairs = (double)n * (double)n;
         return NBODY_OK;
     }
+    if (!bal_wanted(c, n, &by) && c->inplace_sums == 1 && ticket_wanted(c, n, &y)) {
+        if (symmetric) *symmetric = 4;  // block pairs, partial sums added in place (tickets): no slabs, a few accumulation lanes
+        if (block_bodies) *block_bodies = y.block;
+        if (slabs) *slabs = ticket_lanes(c, n, y.nb) > 1 ? ticket_lanes(c, n, y.nb) : 0;
+        if (workgroups) *workgroups = y.grid;
+        if (evaluated_pairs) *evaluated_pairs = ((double)y.nb * (y.nb - 1) / 2 + y.nb) * (double)y.block * (double)y.block;
+        return NBODY_OK;
+    }
     if (bal_wanted(c, n, &by)) {
         if (symmetric) *symmetric = 3;  // symmetric, in balanced runs of rotation steps
         if (block_bodies) *block_bodies = 64 * by.y.bpl;
@@ -453,12 +497,46 @@ int nbody_ctx_step_info(nbody_ctx* c, int n, int* symmetric, int* block_bodies, 
         if (evaluated_pairs) *evaluated_pairs = ((double)y.nb * (y.nb - 1) / 2 + y.nb) * (double)y.block * (double)y.block;
         return NBODY_OK;
     }
+    if (ticket_wanted(c, n, &y)) {   // (auto: the slab workspace does not fit the cap)
+        if (symmetric) *symmetric = 4;
+        if (block_bodies) *block_bodies = y.block;
+        if (slabs) *slabs = ticket_lanes(c, n, y.nb) > 1 ? ticket_lanes(c, n, y.nb) : 0;
+        if (workgroups) *workgroups = y.grid;
+        if (evaluated_pairs) *evaluated_pairs = ((double)y.nb * (y.nb - 1) / 2 + y.nb) * (double)y.block * (double)y.block;
+        return NBODY_OK;
+    }
     const Shape s = resolve_shape(c, n, n);
     if (symmetric) *symmetric = 0;
     if (block_bodies) *block_bodies = nbk::kWG * s.bpl;
     if (slabs) *slabs = s.jsplit;
     if (workgroups) *workgroups = s.blocks_x * s.jsplit;
     if (evaluated_pairs) *evaluated_pairs = (double)n * (double)n;
+    return NBODY_OK;
+}
+
+// Device-free view of the ticket kernel's task list (host tests): which block pair task `task` of an nb-block launch evaluates and
+// which contribution numbers its two sums carry (the closed forms the kernel uses; nbk::force_sym_ticket).
+int nbody_plan_ticket_task(int nb, int task, int* out_i, int* out_j, int* out_seq_i, int* out_seq_j)
+{
+    if (nb < 2 || task < 0 || task >= nb * (nb - 1) / 2 + nb) return fail(NBODY_ERR_INVALID, "bad ticket task: nb=%d task=%d", nb, task);
+    const int npair = nb * (nb - 1) / 2;
+    int I, J, si, sj = -1;
+    if (task >= npair) {
+        I = J = task - npair;
+        si = nb - 1;
+    } else {
+        int r = 0;
+        while (r < nb - 2 && (int)(((long)(r + 1) * (2L * nb - (r + 1) - 1)) / 2) <= task) ++r;   // row of the triangular list = anti-diagonal d - 1
+        const int c0 = task - (int)(((long)r * (2L * nb - r - 1)) / 2), d = r + 1;
+        I = c0;
+        J = c0 + d;
+        si = (d - 1) + (d < I ? d : I);
+        sj = (d - 1 < nb - 1 - J ? d - 1 : nb - 1 - J) + (d - 1);
+    }
+    if (out_i) *out_i = I;
+    if (out_j) *out_j = J;
+    if (out_seq_i) *out_seq_i = si;
+    if (out_seq_j) *out_seq_j = sj;
     return NBODY_OK;
 }
 

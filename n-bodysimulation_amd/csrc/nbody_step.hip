@@ -173,6 +173,28 @@ int launch_sym_untimed(nbody_ctx* c, const SymShape& y0, const nbk::SymParams& p
     return NBODY_OK;
 }
 
+// block pairs with the sums added in place: the whole task list in ONE launch (a ticket waits only for EARLIER tasks of the same launch)
+int launch_ticket(nbody_ctx* c, const SymShape& y, const nbk::SymParams& p, bool timed)
+{
+    if (timed) if (int rc = time_mark(c)) return rc;
+    if (y.bpl == 10 && y.waves == 4) nbk::force_sym_ticket<nbk::SymPacked<10>, 4><<<y.grid, 256, 0, c->stream>>>(p);
+    else if (y.bpl == 10 && y.waves == 1) nbk::force_sym_ticket<nbk::SymPacked<10>, 1><<<y.grid, 64, 0, c->stream>>>(p);
+    else return fail(NBODY_ERR_CONFIG, "no in-place block-pair kernel for waves=%d bodies_per_lane=%d", y.waves, y.bpl);
+    HIP_TRY(hipGetLastError());
+    if (timed) return time_mark(c);
+    return NBODY_OK;
+}
+
+void ticket_params(nbody_ctx* c, nbk::SymParams* sp, const float4* x, int i0, int n, const SymShape& y, float4* acc, int lanes)
+{
+    sym_square_params(sp, x, i0, n, y, nullptr, c->eps2);
+    sp->acc = acc;
+    sp->tickets = c->tickets;
+    sp->err = c->terr_dev;
+    sp->acc_lanes = lanes;
+    sp->acc_stride = n;
+}
+
 int launch_run(nbody_ctx* c, const RunShape& y, const nbk::RunParams& p)
 {
     if (int rc = time_mark(c)) return rc;
@@ -613,10 +635,11 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
         }
         return NBODY_OK;
     }
+    if (int rc = ticket_error(c)) return rc;
     SymShape y{};
     RunShape ry{};
     BalShape by{};
-    bool bal = false, runs = false, sym = false;
+    bool bal = false, runs = false, sym = false, tick = false;
     for (int attempt = 0;; ++attempt) {   // a symmetric footprint that cannot be allocated lowers the cap: resolve again
         bal = bal_wanted(c, n, &by);
         if (bal) {
@@ -625,9 +648,14 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
             if (rc != NBODY_ERR_NOMEM || attempt >= 16) return rc;
             continue;
         }
+        tick = c->inplace_sums == 1 && ticket_wanted(c, n, &y);   // asked for: instead of unit runs / block pairs with slabs
+        if (tick) break;
         runs = run_wanted(c, n, &ry);
         sym = !runs && sym_wanted(c, n, &y);
-        if (!runs && !sym) break;
+        if (!runs && !sym) {
+            tick = ticket_wanted(c, n, &y);   // no slab workspace to be had for the symmetric kernels: the sums go in place
+            break;
+        }
         const int rc = ensure_slabs(c, (runs ? (size_t)ry.max_slabs : (size_t)y.nb) * n * sizeof(float4));
         if (rc == NBODY_OK) break;
         if (rc != NBODY_ERR_NOMEM || attempt >= 16) return rc;
@@ -669,6 +697,21 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
         q.slabs = static_cast<const float4*>(c->slabs);
         q.nslab = y.nb;
         q.slab_stride = n;
+    } else if (tick) {
+        if (int rc = ensure_tickets(c)) return rc;
+        int lanes = ticket_lanes(c, n, y.nb);
+        while (lanes > 1 && ensure_slabs(c, (size_t)lanes * n * sizeof(float4)) != NBODY_OK) lanes /= 2;   // (an allocation that fails: fewer lanes)
+        if (lanes > 1) {   // the lanes live in the workspace; the integrate adds them in index order
+            ticket_params(c, &sp, reinterpret_cast<const float4*>(d_bodies), 0, n, y, static_cast<float4*>(c->slabs), lanes);
+            q.slabs = static_cast<const float4*>(c->slabs);
+            q.nslab = lanes;
+            q.slab_stride = n;
+        } else {           // one lane: the sums land in the acceleration array itself, no workspace at all
+            ticket_params(c, &sp, reinterpret_cast<const float4*>(d_bodies), 0, n, y, q.a, 1);
+            q.slabs = nullptr;
+            q.nslab = 0;
+            q.slab_stride = 0;
+        }
     } else {
         p.x = reinterpret_cast<const float4*>(d_bodies);
         p.i0 = 0; p.i1 = n; p.j0 = 0; p.j1 = n;
@@ -697,7 +740,7 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
     // bits (the generation number would be frozen into a captured graph). Same size rule as nbody_accel_range, so that a step and
     // the accel + integrate pair it is made of keep giving the same bits.
     constexpr int kEqRescanSteps = 1024;
-    const bool eq_path = (bal || runs || sym) && !graphable;
+    const bool eq_path = (bal || runs || sym || tick) && !graphable;
     auto scan_masses = [&]() -> int {
         const nbk::MassInfo* q = nullptr;
         unsigned int gen = 0;
@@ -717,6 +760,7 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
             return launch_bal_reduce(c, brp);   // the inbox sum and the integrate in one kernel
         }
         if (runs) rc = launch_run(c, ry, rp);
+        else if (tick) rc = launch_ticket(c, y, sp, timed);
         else if (sym) rc = timed ? launch_sym(c, y, sp) : launch_sym_untimed(c, y, sp);
         else rc = timed ? launch_force(c, s, p) : launch_force_untimed(c, s, p);
         if (rc != NBODY_OK) return rc;
@@ -728,8 +772,8 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
     if (graphable && steps >= kGraphChunk) {
         // Launch-bound regime: replay a captured chain of kGraphChunk steps instead of 2*kGraphChunk
         // host launches. The kernels and their order are exactly those of the loop below.
-        const nbody_ctx::GraphKey key{d_bodies, q.a, q.v, c->slabs, n, bal ? by.y.bpl : runs ? ry.bpl : sym ? y.bpl : s.bpl,
-                                      bal ? -2 : runs ? -1 : sym ? y.waves : s.tile, bal ? by.y.L : runs ? ry.layout.L : sym ? y.nb : s.jsplit,
+        const nbody_ctx::GraphKey key{d_bodies, q.a, q.v, c->slabs, n, bal ? by.y.bpl : runs ? ry.bpl : (sym || tick) ? y.bpl : s.bpl,
+                                      bal ? -2 : runs ? -1 : tick ? -3 - y.waves : sym ? y.waves : s.tile, bal ? by.y.L : runs ? ry.layout.L : (sym || tick) ? y.nb : s.jsplit,
                                       c->kernel, kGraphChunk, c->dt, c->eps2, c->stream};
         if (!c->graph_exec || !(key == c->graph_key)) {
             if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }

@@ -136,6 +136,11 @@ class Context:
         more are not chosen; the step falls back towards the one-sided kernel. fail_above=True is the test hook of nbody.h."""
         check(self._lib.nbody_ctx_set_workspace_limit(self._h, nbytes, 1 if fail_above else 0))
 
+    def set_inplace_sums(self, mode: int = -1) -> None:
+        """Block pairs with the partial sums added in place (no slab workspace): -1 where the slab workspace does not fit the cap,
+        1 wherever unit runs / block pairs would run, 0 never."""
+        check(self._lib.nbody_ctx_set_inplace_sums(self._h, mode))
+
     def set_stream(self, stream: Optional[torch.cuda.Stream]) -> None:
         self._stream = stream  # keep it alive
         check(self._lib.nbody_ctx_set_stream(self._h, C.c_void_p(stream.cuda_stream) if stream is not None else None))
@@ -159,7 +164,7 @@ class Context:
     def _info(self, fn, *args) -> dict:
         sym, blk, slabs, wgs, ev = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_double()
         check(fn(self._h, *args, C.byref(sym), C.byref(blk), C.byref(slabs), C.byref(wgs), C.byref(ev)))
-        return {"symmetric": sym.value > 0, "runs": sym.value == 2, "balanced": sym.value == 3, "fused": sym.value == -1,
+        return {"symmetric": sym.value > 0, "runs": sym.value == 2, "balanced": sym.value == 3, "fused": sym.value == -1, "ticket": sym.value == 4,
                 "block_bodies": blk.value, "slabs": slabs.value, "workgroups": wgs.value, "evaluated_pairs": ev.value}
 
     def step_info_f64(self, n: int) -> dict:

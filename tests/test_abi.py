@@ -284,3 +284,84 @@ def test_autotune_decision_rule(nb):
     assert decide(20.0, 20.0, 19.0, arr(20.1, 19.2, 20.3), arr(19.0, 19.1, 18.9)) == 0    # one built-in trial as fast as the challenger
     assert decide(20.0, 20.0, 19.0, arr(20.1, -1.0, 20.3), arr(19.0, 19.1, 18.9)) == 0    # a failed trial
     assert decide(0.0, 20.0, 19.0) == 0 and decide(20.0, 20.0, 0.0) == 0 and decide(20.0, 20.0, 19.0, m=0.0) == 0
+
+
+def test_report_structs_have_the_layout_the_python_binding_assumes(tmp_path):
+    """nbody_clock_report / nbody_comm_report_t are filled by the library and read through ctypes: sizes and field offsets of the two
+    sides must agree (compiled from include/nbody.h with the host C compiler; no GPU)."""
+    import ctypes
+    import subprocess
+    import nbody_amd as nb
+    src = tmp_path / "layout.c"
+    fields = {"nbody_clock_report": [f for f, _ in nb._lib.ClockReport._fields_], "nbody_comm_report_t": [f for f, _ in nb._lib.CommReport._fields_]}
+    body = "".join(f'printf("{t} %zu", sizeof({t}));' + "".join(f'printf(" %zu", offsetof({t}, {f}));' for f in fs) + 'printf("\\n");' for t, fs in fields.items())
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "nbody.h"\nint main(void){' + body + 'return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    for line, (t, cls) in zip(out, (("nbody_clock_report", nb._lib.ClockReport), ("nbody_comm_report_t", nb._lib.CommReport))):
+        nums = [int(v) for v in line.split()[1:]]
+        assert nums[0] == ctypes.sizeof(cls), (t, nums[0], ctypes.sizeof(cls))
+        assert nums[1:] == [getattr(cls, f).offset for f, _ in cls._fields_], t
+
+
+def test_multi_gpu_line_reads_against_its_own_single_gpu_point_and_prediction():
+    """bench.py's multi-GPU extras (pure host logic): scaling_efficiency = value / (G x single_gpu_same_n.value) and the predicted step
+    time from DESIGN.md 5's per-rank compute-side efficiency; the launch-weighted merge of per-repeat clock records."""
+    import importlib.util
+    import types
+    spec = importlib.util.spec_from_file_location("bench_mod3", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    same_n = {"ms_per_step": 171.46, "value": 1048576.0 ** 2 / 171.46e-3}
+    R = types.SimpleNamespace(world=8)
+    f = b.scaling_fields(R, value=1048576.0 ** 2 / 22.1e-3, ms_per_step=22.1, same_n=same_n)
+    assert abs(f["scaling_efficiency"] - 171.46 / (8 * 22.1)) < 1e-12
+    p = f["predicted_ms_per_step"]
+    assert abs(p["low"] - 171.46 / 8 / 0.976) < 1e-9 and abs(p["high"] - p["low"] - 0.3) < 1e-12 and p["measured"] == 22.1
+    assert 21.9 < p["low"] < 22.0 and 22.2 < p["high"] < 22.3                      # DESIGN.md 5: 22.0-22.3 ms at G = 8 from a 171.46-ms step
+    assert b.scaling_fields(types.SimpleNamespace(world=1), 1.0, 1.0, same_n) == {} and b.scaling_fields(R, 1.0, 1.0, None) == {}
+    one = {"launches": 20, "xcds": 8, "unpaired": 0, "cycles_per_launch": 2.4e7, "cycles_per_launch_min": 2.39e7, "cycles_per_launch_max": 2.41e7,
+           "ticks_per_launch": 1.0e6, "sclk_mhz": 2400.0, "sclk_mhz_min_xcd": 2380.0, "sclk_mhz_max_xcd": 2420.0}
+    two = dict(one, launches=60, cycles_per_launch=2.4e7, ticks_per_launch=1.2e6, sclk_mhz=2000.0, sclk_mhz_min_xcd=1990.0, sclk_mhz_max_xcd=2010.0)
+    m = b.merge_clock([one, two, {"launches": 0, "sclk_mhz": 0}, None])
+    assert m["launches"] == 80 and abs(m["ticks_per_launch"] - (20 * 1.0e6 + 60 * 1.2e6) / 80) < 1e-6
+    assert abs(m["sclk_mhz"] - 2.4e7 / m["ticks_per_launch"] * 100.0) < 1e-9 and m["sclk_mhz_min_xcd"] == 1990.0 and m["sclk_mhz_max_repeat"] == 2400.0
+    assert b.merge_clock([]) is None
+
+
+def test_ticket_task_list_gives_every_block_its_contributions_in_order():
+    """nbody_plan_ticket_task (the closed forms nbk::force_sym_ticket uses): walking the task list in launch order, every block receives
+    contributions 0, 1, ..., nb-1 exactly once and in that order — so a contribution's predecessor always belongs to an EARLIER task (a
+    waiting workgroup never waits for one that starts after it) — every unordered block pair occurs once, the diagonal block is each
+    block's last contribution, and a block meets at most two tasks per anti-diagonal (what keeps concurrent tasks off one ticket)."""
+    import ctypes as C
+    import nbody_amd as nb
+    lib = nb.load()
+    for nbk in (2, 3, 4, 7, 16, 103, 410):
+        count = [0] * nbk
+        pairs = set()
+        ntasks = nbk * (nbk - 1) // 2 + nbk
+        last_d, seen_in_d = 0, {}
+        for t in range(ntasks):
+            i, j, si, sj = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            nb._lib.check(lib.nbody_plan_ticket_task(nbk, t, C.byref(i), C.byref(j), C.byref(si), C.byref(sj)))
+            I, J = i.value, j.value
+            assert 0 <= I <= J < nbk and (I, J) not in pairs
+            pairs.add((I, J))
+            assert si.value == count[I], (nbk, t, I, J, si.value, count[I])
+            count[I] += 1
+            if I != J:
+                assert sj.value == count[J], (nbk, t, I, J, sj.value, count[J])
+                count[J] += 1
+                d = J - I
+                assert d >= last_d                                       # anti-diagonal by anti-diagonal
+                if d != last_d:
+                    last_d, seen_in_d = d, {}
+                for b in (I, J):
+                    seen_in_d[b] = seen_in_d.get(b, 0) + 1
+                    assert seen_in_d[b] <= 2
+            else:
+                assert sj.value == -1 and si.value == nbk - 1           # the diagonal block closes the count
+        assert count == [nbk] * nbk and len(pairs) == ntasks
+    assert lib.nbody_plan_ticket_task(1, 0, None, None, None, None) != 0 and lib.nbody_plan_ticket_task(4, 10, None, None, None, None) != 0

@@ -141,3 +141,12 @@ def test_developer_probes_still_compile_against_the_product_headers(tool):
                         "-I", os.path.join(ROOT, "n-bodysimulation_amd", "csrc"), "-I", os.path.join(ROOT, "include"),
                         os.path.join(ROOT, "tools", tool + ".hip")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_in_place_block_pair_kernels_keep_the_slab_kernel_s_occupancy(nb, kernels):
+    """nbk::force_sym_ticket (sums added in place): same rotation pass, same registers-per-wave class (two waves per SIMD at ten bodies
+    per lane) and the same LDS as the slab kernel of its shape."""
+    for w in (4, 1):
+        r = _get(kernels, f"nbk::force_sym_ticket<nbk::SymPacked<10>, {w}>")
+        assert r["Occupancy"] == nb.load().nbody_plan_symmetric_occupancy(10) and r["AGPRs"] == 0, r
+        assert r["LDS Size"] == 64 * w * 10 * 16

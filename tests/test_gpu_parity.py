@@ -1044,30 +1044,123 @@ def test_partial_sum_workspace_beyond_2p31_elements(nb, oracle):
 # ---- workspace cap and fallback (the symmetric kernels' O(N^2/B) partial-sum slabs) ---------------------------------
 
 def test_workspace_limit_steers_the_shape_choice_and_keeps_the_result(nb, oracle):
-    """nbody_ctx_set_workspace_limit: a symmetric decomposition whose slabs exceed the cap is not chosen — the step falls
-    back to a smaller footprint, finally to the one-sided kernel — and the answer stays within the fast tolerances."""
+    """nbody_ctx_set_workspace_limit: a slab decomposition whose workspace exceeds the cap is not chosen. A whole step then keeps the
+    symmetric arithmetic with the sums added in place (no workspace); with that switched off (nbody_ctx_set_inplace_sums(0)) it falls
+    back to a smaller footprint, finally to the one-sided kernel. The answer stays within the fast tolerances either way."""
     n = 20000
     x0 = nb.engine.seeded_bodies(n, 1, 21)
     truth = oracle.accel_range(x0, 0, 2048, 0, n, eps2=0.002, f64acc=True)
     sim = nb.engine.Simulation(x0, dt=0.01, eps2=0.002)
     free_choice = sim.ctx.step_info(n)
-    assert free_choice["symmetric"]
+    assert free_choice["symmetric"] and not free_choice["ticket"]
     need = free_choice["slabs"] * n * 16
     sim.run(1)
     a_free = sim.state()[2]
-    for limit, want_symmetric in ((need // 2, None), (7 * n * 16, False), (1, False)):   # the largest block (2560 bodies) needs 8 slabs
-        s2 = nb.engine.Simulation(x0, dt=0.01, eps2=0.002)
-        s2.ctx.set_workspace_limit(limit)
-        info = s2.ctx.step_info(n)
-        assert info["slabs"] * n * 16 <= limit or not info["symmetric"]     # the one-sided kernel's <= 64 slabs are always allowed
-        if want_symmetric is not None:
-            assert info["symmetric"] == want_symmetric
-        s2.run(1)
-        a = s2.state()[2]
-        assert np.abs(a[:2048] - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 1e-5
-        assert np.abs(a - a_free)[:, :3].max() / np.abs(a_free[:, :3]).max() <= 1e-5
-        s2.ctx.set_workspace_limit(0)                                        # automatic again: the free choice is back
-        assert s2.ctx.step_info(n) == free_choice
+    for inplace in (-1, 0):
+        for limit, unconstrained_kind in ((need // 2, None), (7 * n * 16, False), (1, False)):   # the largest block (2560 bodies) needs 8 slabs
+            s2 = nb.engine.Simulation(x0, dt=0.01, eps2=0.002)
+            s2.ctx.set_inplace_sums(inplace)
+            s2.ctx.set_workspace_limit(limit)
+            info = s2.ctx.step_info(n)
+            assert info["slabs"] * n * 16 <= limit or not info["symmetric"]     # the one-sided kernel's <= 64 slabs are always allowed
+            if unconstrained_kind is not None:
+                if inplace == 0:
+                    assert not info["symmetric"] and not info["ticket"]          # the older fallback: one-sided
+                else:
+                    assert info["symmetric"] and info["ticket"] and info["slabs"] in (0, 2, 4, 8)   # block pairs, sums in place (lanes under the cap)
+            s2.run(1)
+            a = s2.state()[2]
+            assert np.abs(a[:2048] - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 1e-5
+            assert np.abs(a - a_free)[:, :3].max() / np.abs(a_free[:, :3]).max() <= 1e-5
+            s2.ctx.set_workspace_limit(0)                                        # automatic again: the free choice is back
+            assert s2.ctx.step_info(n) == free_choice
+
+
+@pytest.mark.parametrize("n,kernel", [(1300, "symmetric"), (5000, "symmetric"), (20001, "symmetric"), (70000, "fast")])
+def test_in_place_block_sums_vs_oracle(nb, oracle, n, kernel):
+    """nbk::force_sym_ticket — block pairs with the partial sums added straight into the acceleration array, the order fixed per block
+    by a ticket: against the Jacobi oracle and fp64-accumulated truth (T2 bars), bit-identical run to run, and within rounding of the
+    slab kernel (the same block sums in another fixed order). Ragged sizes: the last block is partly padding."""
+    k = nb.KERNEL_SYMMETRIC if kernel == "symmetric" else nb.KERNEL_FAST
+    x0 = nb.engine.seeded_bodies(n, 0 if n < 10000 else 1, 31 + n)
+    dt = 0.1 if n < 10000 else 0.01
+    steps = 3 if n < 30000 else 1
+    runs = []
+    for rep in range(2):
+        sim = nb.engine.Simulation(x0, dt=dt, eps2=0.002, kernel=k)
+        sim.ctx.set_inplace_sums(1)
+        info = sim.ctx.step_info(n)
+        assert info["ticket"] and info["symmetric"] and info["slabs"] in (0, 2, 4, 8) and info["block_bodies"] in (640, 2560), info
+        sim.run(steps)
+        runs.append(sim.state())
+    for p, q in zip(*runs):
+        assert np.array_equal(p, q)                                   # the tickets fix the order: the same bits every run
+    x, v, a = runs[0]
+    slab = nb.engine.Simulation(x0, dt=dt, eps2=0.002, kernel=nb.KERNEL_SYMMETRIC)
+    slab.ctx.set_inplace_sums(0)
+    slab.ctx.set_symmetric_shape(1 if info["block_bodies"] == 640 else 4, 10)
+    assert not slab.ctx.step_info(n)["ticket"]
+    slab.run(steps)
+    xs, vs, as_ = slab.state()
+    scale = np.abs(as_[:, :3]).max()
+    assert np.abs(a - as_)[:, :3].max() / scale <= 2e-6 and np.abs(x - xs)[:, :3].max() <= 1e-6 * max(1.0, np.abs(xs[:, :3]).max())
+    assert np.all(a[:, 3] == 0)
+    if n <= 20001:
+        xo, vo, ao = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
+        oracle.step_jacobi(xo, ao, vo, dt=dt, eps2=0.002, steps=steps)
+        assert np.abs(a - ao)[:, :3].max() / np.abs(ao[:, :3]).max() <= 1e-5
+        assert np.abs(x - xo)[:, :3].max() <= 1e-6 * max(1.0, np.abs(xo[:, :3]).max())
+    else:
+        m = 1024
+        truth = oracle.accel_range(x0, n - m, n, 0, n, eps2=0.002, f64acc=True)      # the ragged last block included
+        sim1 = nb.engine.Simulation(x0, dt=dt, eps2=0.002, kernel=k)
+        sim1.ctx.set_inplace_sums(1)
+        sim1.run(1)
+        a1 = sim1.state()[2]
+        assert np.abs(a1[n - m:] - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 1e-5
+
+
+def test_workspace_limit_at_a_quarter_keeps_the_symmetric_step_at_n262144(nb, oracle):
+    """configs[2]'s size with the workspace capped at a quarter of the slab kernel's footprint: the step keeps the
+    symmetric arithmetic — block pairs, sums in place, no workspace — instead of falling to the one-sided kernel (-30 %): within 1e-5 of
+    max|a| of the CPU's fp64-accumulated sums on sampled bodies, bit-identical run to run, and its step time within a few per cent of the
+    unconstrained one (measured here over 10 queued steps each, same process; the bar is loose enough for a shared box)."""
+    import time
+    n = 262144
+    x0 = nb.engine.seeded_bodies(n, 1, 12345)
+    free = nb.engine.Simulation(x0, dt=0.01, eps2=0.002)
+    free.ctx.set_equal_mass(0)
+    fi = free.ctx.step_info(n)
+    assert fi["symmetric"] and fi["slabs"] == 103 and not fi["ticket"]
+    capped = nb.engine.Simulation(x0, dt=0.01, eps2=0.002)
+    capped.ctx.set_equal_mass(0)
+    capped.ctx.set_workspace_limit(fi["slabs"] * n * 16 // 4)
+    ci = capped.ctx.step_info(n)
+    assert ci["ticket"] and ci["symmetric"] and ci["slabs"] == 8 and ci["block_bodies"] == 2560, ci      # 8 lanes = 32 MiB of the 103-MiB cap
+    capped.run(1)
+    a1 = capped.state()[2]
+    again = nb.engine.Simulation(x0, dt=0.01, eps2=0.002)
+    again.ctx.set_equal_mass(0)
+    again.ctx.set_workspace_limit(fi["slabs"] * n * 16 // 4)
+    again.run(1)
+    assert np.array_equal(a1, again.state()[2])                       # deterministic
+    m = 512
+    for i0 in (0, 131072 - 256, n - m):
+        truth = oracle.accel_range(x0, i0, i0 + m, 0, n, eps2=0.002, f64acc=True)
+        assert np.abs(a1[i0:i0 + m] - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 1e-5
+    free.run(1)
+    assert np.abs(a1 - free.state()[2])[:, :3].max() / np.abs(a1[:, :3]).max() <= 2e-6
+    t = {}
+    for name, s in (("free", free), ("capped", capped), ("free2", free), ("capped2", capped)):
+        s.run(3, sync=False)
+        s.ctx.sync()
+        t0 = time.perf_counter()
+        s.run(10, sync=False)
+        s.ctx.sync()
+        t[name] = (time.perf_counter() - t0) / 10
+    ratio = min(t["capped"], t["capped2"]) / min(t["free"], t["free2"])
+    print(f"N=262144 step: unconstrained {min(t['free'], t['free2']) * 1e3:.3f} ms, capped at a quarter (sums in place) {min(t['capped'], t['capped2']) * 1e3:.3f} ms, ratio {ratio:.4f}")
+    assert ratio < 1.10, t
 
 
 def test_failed_workspace_allocation_falls_back_instead_of_erroring(nb, oracle):
@@ -1086,7 +1179,11 @@ def test_failed_workspace_allocation_falls_back_instead_of_erroring(nb, oracle):
     ctx.sync()
     got = a.cpu().numpy()
     assert np.abs(got[:1024] - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 1e-5
-    assert not ctx.step_info(n)["symmetric"]                        # the cap now sits below every symmetric footprint
+    assert ctx.step_info(n)["ticket"]                               # the cap now sits below every slab footprint: a whole step adds in place
+    ctx.set_inplace_sums(0)
+    assert not ctx.step_info(n)["symmetric"]                        # ... or, with that switched off, runs the one-sided kernel
+    ctx.step(x, a, v, 1)
+    ctx.sync()
     out = torch.zeros_like(x)
     ctx.accel_range(x, out, 0, n, 0, n)                             # the square block through nbody_accel_range: same
     ctx.sync()

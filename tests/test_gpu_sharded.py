@@ -281,6 +281,39 @@ def test_sharded_simulation_multi_rank_over_gloo(nb, oracle, world, n, kernel):
             assert np.abs(a - ao)[:, :3].max() / np.abs(ao[:, :3]).max() <= 1e-5
         assert np.array_equal(x, res[0][1])
         assert rep["steps"] == steps and rep["schedule"] == ("canonical" if kernel == 1 else "symmetric")
+        # mean and maximum over the timed steps (the first step after the upload carries no all-gather)
+        assert rep["gathers"] == steps - 1 and rep["records_kept"] == steps
+        assert rep["all_gather_ms_max"] >= rep["all_gather_ms_avg"] > 0 and rep["exposed_ms_max"] >= rep["exposed_ms_avg"] >= 0
+        if kernel != 1:
+            assert rep["exchanges"] == steps and rep["exchange_ms_max"] >= rep["exchange_ms_avg"] > 0
+            assert rep["exchange_exposed_ms_max"] >= rep["exchange_exposed_ms_avg"] >= 0
+
+
+def test_comm_timing_keeps_a_ring_of_step_records(nb):
+    """200 timed steps of a two-rank machine (both ranks driven from this thread, the collectives plain device copies): the shard
+    keeps 64 step records, folds the older ones into its sums, and the report still covers all 200 steps — mean and maximum."""
+    import ctypes as C
+    L = nb._lib
+    n, world, steps = 4096, 2, 200
+    x0 = nb.engine.seeded_bodies(n, 1, 5)
+    m = _OneThreadRanks(nb, x0, world, nb.KERNEL_SYMMETRIC, 0.01, 0.002, sym_shape=(1, 2))
+    for sh in m.shards:
+        L.check(m.lib.nbody_shard_comm_timing(sh, 1))
+    m.step(steps)
+    for sh in m.shards:
+        r = L.CommReport()
+        L.check(m.lib.nbody_shard_comm_report_ex(sh, C.byref(r)))
+        assert r.steps == steps and r.records_kept == 64 and r.gathers == steps - 1 and r.exchanges == steps
+        assert r.gather_ms_max >= r.gather_ms >= 0 and r.exchange_ms_max >= r.exchange_ms >= 0      # (these callbacks copy on torch's stream: the bracketed interval is empty)
+        assert r.gather_exposed_ms_max >= r.gather_exposed_ms >= 0 and r.exchange_exposed_ms_max >= r.exchange_exposed_ms >= 0
+        k = C.c_int()
+        g, ge, x, xe = (C.c_double() for _ in range(4))
+        L.check(m.lib.nbody_shard_comm_report(sh, C.byref(k), C.byref(g), C.byref(ge), C.byref(x), C.byref(xe)))   # the means-only form agrees
+        assert k.value == steps and g.value == r.gather_ms and xe.value == r.exchange_exposed_ms
+        L.check(m.lib.nbody_shard_comm_timing(sh, 1))                                  # starts afresh
+        L.check(m.lib.nbody_shard_comm_report_ex(sh, C.byref(r)))
+        assert r.steps == 0 and r.gathers == 0 and r.gather_ms == 0
+    m.close()
 
 
 def _nccl_worker(rank, world, port, n, steps, q):

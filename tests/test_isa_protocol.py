@@ -138,3 +138,75 @@ def test_the_checker_itself_sees_a_missing_drain():
     skipped[0] = (skipped[0][0], "s_cbranch_execz", "2", skipped[3][0])          # jumps in behind the wait: waves that skipped are fine, but flag the shape
     with pytest.raises(AssertionError):
         check_drain_before_final_barrier("skipped", skipped)
+
+
+# ---- the second cross-workgroup protocol: block pairs with the sums added in place (nbk::force_sym_ticket) ------------------------------
+
+def _ticket_kernels(isa):
+    return sorted(n for n in isa if "force_sym_ticket" in n)
+
+
+def check_ticket_hand_over(name, insns, waves):
+    """Every store that hands a ticket on (global_store_dword sc1 outside the spin loop) comes after: the workgroup's last accumulation
+    store (global_store_dwordx2 sc1), an s_waitcnt vmcnt(0) executed by every wave, and — several waves — the barrier. Returns the
+    number of hand-over stores found."""
+    handed = 0
+    for k, (addr, op, args, _) in enumerate(insns):
+        if op != "global_store_dword" or "sc1" not in args or "sc0" in args:
+            continue
+        back = insns[max(0, k - 60):k]
+        last_acc = max((q for q, (_, o, a, _) in enumerate(back) if o == "global_store_dwordx2" and "sc1" in a), default=None)
+        spin = max((q for q, (_, o, _, _) in enumerate(back) if o == "s_memrealtime"), default=None)
+        if spin is not None and (last_acc is None or spin > last_acc):
+            continue                                             # the abort flag, raised inside the spin loop: not a hand-over
+        assert last_acc is not None, (name, f"ticket store at 0x{addr:x} with no accumulation store in front of it")
+        tail = back[last_acc + 1:]
+        waits = [q for q, (_, o, a, _) in enumerate(tail) if _drains_vm(o, a)]
+        assert waits, (name, f"no s_waitcnt vmcnt(0) between the last accumulation store and the ticket store at 0x{addr:x}: the next "
+                             "contributor could load sums that are still on their way")
+        if waves > 1:
+            bars = [q for q, (_, o, _, _) in enumerate(tail) if o == "s_barrier"]
+            assert bars and bars[-1] > waits[0], (name, f"the ticket store at 0x{addr:x} is not behind a barrier that follows the drain")
+        handed += 1
+    return handed
+
+
+def test_in_place_block_pair_kernels_drain_their_sums_before_handing_the_ticket_on(isa):
+    names = _ticket_kernels(isa)
+    assert len(names) == 2, names                                 # <SymPacked<10>, 4> and <SymPacked<10>, 1>
+    for name in names:
+        waves = 4 if "ELi4EEE" in name else 1
+        handed = check_ticket_hand_over(name, isa[name], waves)
+        assert handed >= 4, (name, handed)                        # I side and J side, general and equal-mass path
+
+
+def test_in_place_block_pair_kernels_move_their_sums_at_agent_scope(isa):
+    """The eight XCDs' L2s are not coherent for ordinary accesses: every sum a ticket kernel writes is an agent-scope store
+    (global_store_dwordx2 sc1, through the L2), every sum it reads back an agent-scope load; it writes no slab at all (no plain
+    global_store of partial sums), and its spin loop looks at the tickets with agent-scope loads."""
+    for name in _ticket_kernels(isa):
+        insns = isa[name]
+        stores = [(op, args) for _, op, args, _ in insns if op.startswith("global_store")]
+        assert stores and all("sc1" in args for _, args in stores), (name, [s for s in stores if "sc1" not in s[1]][:3])
+        acc_stores = [1 for op, args in stores if op == "global_store_dwordx2"]
+        acc_loads = [1 for _, op, args, _ in insns if op == "global_load_dwordx2" and "sc1" in args]
+        assert len(acc_stores) >= 2 * 2 * (10 + 1) and len(acc_loads) >= 2 * 2 * (10 + 1), (name, len(acc_stores), len(acc_loads))   # 2 halves x (general, equal-mass) x (10 I-side unrolled + the J-side loop)
+        polls = [1 for _, op, args, _ in insns if op == "global_load_dword" and "sc1" in args]
+        assert len(polls) >= 4, (name, len(polls))
+        assert any(op == "s_memrealtime" for _, op, _, _ in insns) and any(op == "s_sleep" for _, op, _, _ in insns), name   # bounded, polite spin
+
+
+def test_the_ticket_checker_sees_a_missing_drain():
+    def mk(lines):
+        return [(0x100 + 4 * k, op, args, None) for k, (op, args) in enumerate(lines)]
+    good = mk([("global_store_dwordx2", "v[0:1], v[2:3], off sc1"), ("s_waitcnt", "vmcnt(0)"), ("s_barrier", ""), ("global_store_dword", "v0, v1, s[2:3] sc1")])
+    assert check_ticket_hand_over("good", good, 4) == 1
+    no_drain = mk([("global_store_dwordx2", "v[0:1], v[2:3], off sc1"), ("s_waitcnt", "lgkmcnt(0)"), ("s_barrier", ""), ("global_store_dword", "v0, v1, s[2:3] sc1")])
+    with pytest.raises(AssertionError):
+        check_ticket_hand_over("no_drain", no_drain, 4)
+    no_barrier = mk([("global_store_dwordx2", "v[0:1], v[2:3], off sc1"), ("s_waitcnt", "vmcnt(0)"), ("global_store_dword", "v0, v1, s[2:3] sc1")])
+    with pytest.raises(AssertionError):
+        check_ticket_hand_over("no_barrier", no_barrier, 4)
+    assert check_ticket_hand_over("one wave", no_barrier, 1) == 1
+    abort = mk([("s_memrealtime", "s[4:5]"), ("global_store_dword", "v0, v1, s[2:3] sc1"), ("global_store_dword", "v0, v1, s[6:7] sc0 sc1")])
+    assert check_ticket_hand_over("abort", abort, 4) == 0
