@@ -141,7 +141,12 @@ bool ticket_wanted(const nbody_ctx* c, int n, SymShape* out)
     if (!(c->kernel == NBODY_KERNEL_SYMMETRIC || (c->kernel == NBODY_KERNEL_FAST && n >= kSymMinAuto))) return false;
     if (c->sym_runs == 2) return false;                          // balanced runs were asked for explicitly
     SymShape y{};
-    if (c->inplace_sums < 0 && sym_resolve(c, n, &y)) return false;   // auto: the slab kernel wherever its workspace fits
+    if (c->inplace_sums < 0) {
+        // auto: ONLY where the slab kernel would run but for its workspace — it resolves with the cap ignored and not with it. Anything
+        // else that keeps block pairs away (a single block, a shape request nothing matches) keeps meaning what it meant: one-sided.
+        if (sym_resolve(c, n, &y)) return false;
+        if (!sym_resolve(c, n, &y, true)) return false;
+    }
     // Two shapes are built: four waves x ten bodies per lane (2560-body blocks: a task of about a millisecond, its two additions a per
     // cent of it) where that still makes a few thousand tasks, one wave x ten (640-body blocks) below. (The slab kernel's cost estimate
     // does not know the per-task price of the additions and would always pick the finer shape.)

@@ -71,6 +71,11 @@ for stage in $STAGES; do
       [ $rc -eq 0 ] || break
       timeout -k 10 300 python3 bench.py --bodies $n --steps $k --warmup $w --min-seconds 4 --no-cpu-baseline > $OUT/n${n}_bench.json 2> $OUT/n${n}_bench.err; rc=$?
     done
+    for spec in 65536:400:40 131072:100:10 160000:60:6 262144:20:5 1048576:3:1; do   # the same sizes with the block sums added in place (no slabs)
+      IFS=: read n k w <<< "$spec"
+      [ $rc -eq 0 ] || break
+      timeout -k 10 300 python3 bench.py --bodies $n --steps $k --warmup $w --min-seconds 4 --no-cpu-baseline --inplace-sums on > $OUT/n${n}_inplace_bench.json 2> $OUT/n${n}_inplace_bench.err; rc=$?
+    done
     [ $rc -eq 0 ] && { timeout -k 10 300 python3 bench.py --masses random --no-cpu-baseline > $OUT/n262144_random_masses_bench.json 2> $OUT/n262144_random_masses_bench.err; rc=$?; }
     python3 tools/sizes_table.py $OUT | tee $OUT/sizes_table.md ;;
   pmcn)

@@ -23,7 +23,7 @@ def decomposition(launch):
     if launch.get("runs"):
         return f"unit runs ({launch['block_bodies'] // 64}/lane) + integrate"
     if launch.get("ticket"):
-        return f"block pairs, sums in place ({launch['block_bodies']}-body blocks) + integrate"
+        return f"block pairs, sums in place ({launch['block_bodies']}-body blocks, {launch['slabs'] or 1} lane(s)) + integrate"
     if launch.get("symmetric"):
         return f"block pairs ({launch['block_bodies']}-body blocks, {launch['slabs']} slabs) + integrate"
     return "one-sided LDS tiles + integrate"
@@ -33,7 +33,7 @@ def main():
     src = sys.argv[1]
     rows = []
     for f in glob.glob(os.path.join(src, "n*_bench.json")):
-        m = re.match(r"n(\d+)_bench\.json$", os.path.basename(f))
+        m = re.match(r"n(\d+)(?:_inplace)?_bench\.json$", os.path.basename(f))
         if not m:
             continue
         lines = [ln for ln in open(f) if ln.startswith("{")]
@@ -43,7 +43,7 @@ def main():
         n = d["config"]["n_bodies"]
         r = d["roofline"]
         rows.append((n, d, r))
-    rows.sort(key=lambda t: t[0])
+    rows.sort(key=lambda t: (t[0], bool(t[1]['config']['launch'].get('ticket'))))
     print("| N | decomposition | µs / step | interactions / s | frac of peak (step wall time) | frac (force kernel events) | sclk under load (MHz) | frac at that clock | kernel cycles / step |")
     print("|---|---|---|---|---|---|---|---|---|")
     for n, d, r in rows:
