@@ -860,10 +860,12 @@ def offline_traffic(R, symmetric):
     if R.multi or R.f64 or not os.path.exists(tpath):
         return None, None, None
     try:
-        t = json.load(open(tpath))
-        if t.get("n_bodies") == R.n and t.get("symmetric") == symmetric and t.get("slabs") == R.info.get("slabs"):
-            return (t.get("force_kernel_hbm_bytes_per_launch"), t.get("note"),
-                    "OFFLINE PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/gpu_round.sh pmc), kept in profiles/traffic.json for this launch shape; NOT measured in this run")
+        top = json.load(open(tpath))
+        for t in [top] + list(top.get("other_shapes", [])):
+            if (t.get("n_bodies") == R.n and t.get("symmetric") == symmetric and t.get("slabs") == R.info.get("slabs")
+                    and bool(t.get("ticket")) == bool(R.info.get("ticket"))):
+                return (t.get("force_kernel_hbm_bytes_per_launch"), t.get("note"),
+                        "OFFLINE PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/gpu_round.sh pmc), kept in profiles/traffic.json for this launch shape; NOT measured in this run")
     except Exception:
         pass
     return None, None, None

@@ -16,7 +16,8 @@
 #   local8    nbody_headless --ngpu 8 --transport local --share-devices at N = 1048576 under rocprofv3 --stats (and --ngpu 1)
 #   symab     same-box A/B of build/symbench_r04 (an older device header, see below) against build/symbench: NEEDS both binaries
 #   pmc       PMC passes (one counter group per run, --kernel-trace only beside --pmc): the bench's general path, its equal-mass path
-#             (--equal-mass auto), and tools/sync_probe at N = 8192 (the two fused kernels); then tools/pmc_summary.py
+#             (--equal-mass auto), the same step with the block sums added in place (--inplace-sums on: SQ, GRBM, FETCH_SIZE, WRITE_SIZE),
+#             and tools/sync_probe at N = 8192 (the two fused kernels); then tools/pmc_summary.py
 #   rehearse  bench.py --gpus 4 --fake-hosts at N = 1048576 (four RCCL ranks on the one GPU), both transports, started WITHOUT a launcher
 #   pkbank    tools/pkbank_mb: does the VGPR bank of a packed instruction's operands change its issue cost?
 #   multirank only the multi-rank files of the GPU suite (tests/test_gpu_sharded.py, tests/test_zz_rccl_rehearsal.py)
@@ -123,9 +124,11 @@ for stage in $STAGES; do
     done
     python3 tools/symbench_ab_table.py $OUT/symbench_ab.txt | tee $OUT/symbench_ab_table.txt ;;
   pmc)
-    B="python3 $REPO/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-equal-mass-extras"
+    B="python3 $REPO/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-equal-mass-extras --no-clock"
     pmc gen_sq1 $SQ1 $B && pmc gen_grbm $GRBM $B && pmc gen_fetch FETCH_SIZE $B && pmc gen_write WRITE_SIZE $B && \
     pmc eq_sq1 $SQ1 $B --equal-mass auto && pmc eq_grbm $GRBM $B --equal-mass auto && \
+    pmc inplace_sq1 $SQ1 $B --inplace-sums on && pmc inplace_grbm $GRBM $B --inplace-sums on && \
+    pmc inplace_fetch FETCH_SIZE $B --inplace-sums on && pmc inplace_write WRITE_SIZE $B --inplace-sums on && \
     pmc fused_sq1 $SQ1 $REPO/build/sync_probe 8192 300 && pmc fused_grbm $GRBM $REPO/build/sync_probe 8192 300 && pmc fused_sq2 $SQ2 $REPO/build/sync_probe 8192 300; rc=$?
     python3 tools/pmc_summary.py $OUT $OUT/summary ;;
   rehearse)
