@@ -238,8 +238,10 @@ int nbody_ctx_set_workspace_limit(nbody_ctx* ctx, size_t bytes, int fail_above);
  * mode -1 (default): whole steps whose slab workspace does not fit the cap above; 1: every whole step FAST / SYMMETRIC would run as
  * unit runs or block pairs (from 12288 bodies; balanced runs and the fused small-N step keep their own sizes); 0: never (the older
  * fallback: one-sided kernel). The sums differ from the slab kernel's by rounding only (another, equally fixed order of the same
- * nb block sums per body). A workgroup that waited more than 10 s for its turn (never on a healthy run) raises an error that the next
- * nbody_step / nbody_ctx_sync returns. */
+ * nb block sums per body). A workgroup that waited more than 10 s for its turn (never on a healthy run) aborts the launch's remaining waits
+ * and raises an error that the next nbody_step / nbody_ctx_sync returns (the accelerations of that step are incomplete; the tickets are
+ * reset, stepping can go on from restored state). mode 2 is a TEST hook: as 1, and the NEXT in-place launch finds one ticket held by nobody
+ * and gives up after 2 ms — the abort path exercised without a defect to provoke it. */
 int nbody_ctx_set_inplace_sums(nbody_ctx* ctx, int mode);
 
 /* Launch on this HIP stream (a hipStream_t passed as void*; NULL = the context's own stream). */

@@ -492,8 +492,9 @@ int nbody_ctx_set_workspace_limit(nbody_ctx* c, size_t bytes, int fail_above)
 int nbody_ctx_set_inplace_sums(nbody_ctx* c, int mode)
 {
     if (int rc = check_ctx(c)) return rc;
-    if (mode < -1 || mode > 1) return fail(NBODY_ERR_CONFIG, "in-place sums mode must be -1 (auto), 0 (never) or 1 (always)");
-    c->inplace_sums = mode;
+    if (mode < -1 || mode > 2) return fail(NBODY_ERR_CONFIG, "in-place sums mode must be -1 (auto), 0 (never), 1 (always) or 2 (always + the stall test hook)");
+    c->inplace_sums = mode == 2 ? 1 : mode;
+    c->ticket_test_stall = mode == 2;
     return NBODY_OK;
 }
 

@@ -78,7 +78,9 @@ struct nbody_ctx {
     // block pairs with the sums added IN PLACE (nbk::force_sym_ticket: no slab workspace)
     int inplace_sums = -1;     // -1 auto: where the slab workspace of the block-pair kernel does not fit the cap (instead of the one-sided kernel);
                                //  0 never; 1 wherever FAST / SYMMETRIC would run unit runs or block pairs
-    unsigned* tickets = nullptr;     // device: one word per block (kSymMaxSlabs of them), zero between launches
+    bool ticket_test_stall = false;  // TEST hook (nbody_ctx_set_inplace_sums(ctx, 2)), one shot: the next in-place launch finds block 0's first ticket held
+                                     // and may wait 2 ms — exercises the abort / error path without a defect to provoke it
+    unsigned* tickets = nullptr;     // device: one word per (block, lane), zero between launches, + the abort word
     unsigned* terr = nullptr;        // host-mapped: a ticket wait timed out (the launch's sums are not to be trusted)
     unsigned* terr_dev = nullptr;
     void* xslabs = nullptr;    // workspace of nbody_accel_cross (its own, so that a square evaluation issued in parts

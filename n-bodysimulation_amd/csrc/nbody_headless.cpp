@@ -62,7 +62,7 @@ static bool read_file(const std::string& path, void* p, size_t bytes)
 
 int main(int argc, char** argv)
 {
-    int n = N_BODIES, steps = 10, kernel = NBODY_KERNEL_FAST, sync_each = 0, interactive = 0, json = 1, ngpu = 1, timeout_s = 900, autotune = 0, equal_mass = -1;
+    int n = N_BODIES, steps = 10, kernel = NBODY_KERNEL_FAST, sync_each = 0, interactive = 0, json = 1, ngpu = 1, timeout_s = 900, autotune = 0, equal_mass = -1, inplace_sums = -1;
     std::string transport = "rccl";   // --ngpu: rccl (librccl, one GPU per rank) | local (hipMemcpyPeerAsync pulls between the rank threads, no RCCL)
     bool share_devices = false;
     bool f64 = false, force_shard = false;
@@ -94,6 +94,7 @@ int main(int argc, char** argv)
         else if (a == "--load") load = val();
         else if (a == "--sync-each-step") sync_each = 1;
         else if (a == "--no-equal-mass") equal_mass = 0;  // nbody_ctx_set_equal_mass(0): the general pair arithmetic whatever the masses
+        else if (a == "--inplace-sums") { std::string q = val(); if (q != "auto" && q != "on" && q != "off") die("--inplace-sums auto|on|off"); inplace_sums = q == "on" ? 1 : q == "off" ? 0 : -1; }   // nbody_ctx_set_inplace_sums: block sums added in place (no slab workspace)
         else if (a == "--autotune") autotune = 1;        // measure the decompositions on this device first (single GPU, fast kernel)
         else if (a == "--interactive") interactive = 1;
         else if (a == "--quiet") json = 0;
@@ -319,6 +320,7 @@ int main(int argc, char** argv)
     ok(nbody_ctx_set_params(ctx, dt, eps2));
     ok(nbody_ctx_set_kernel(ctx, kernel, 0, 0, 0));
     ok(nbody_ctx_set_equal_mass(ctx, equal_mass));
+    ok(nbody_ctx_set_inplace_sums(ctx, inplace_sums));
     ok(nbody_ctx_reserve(ctx, n));
     if (autotune && kernel == NBODY_KERNEL_FAST && n > 0) {
         int choice = 0;

@@ -372,6 +372,7 @@ struct SymParamsT {
     unsigned* tickets;
     unsigned* err;
     int acc_lanes, acc_stride;
+    int acc_timeout_us;   // how long a wait may last before the launch is aborted and flagged (10 s; the test hook sets milliseconds)
 };
 using SymParams = SymParamsT<float4, float>;
 using SymParamsF64 = SymParamsT<double4, double>;
@@ -643,7 +644,7 @@ enum SymCase : int { kSymGeneral = 0, kSymSquare = 1, kSymRect = 2, kSymTicket =
 // is always resident and never waits: no deadlock; and should a wait exceed ten seconds all the same (a stopped predecessor), the
 // waiter raises the host-mapped error word and goes on — a wrong, flagged result instead of a hung GPU (the host checks the word at
 // its next synchronisation and returns an error).
-constexpr unsigned long long kTicketTimeoutTicks = 1000000000ull;   // 10 s of the 100-MHz counter
+constexpr int kTicketTimeoutUs = 10000000;   // 10 s: what a wait may last on a product launch
 
 __device__ __forceinline__ float4 load_f4_agent(const float4* src)
 {
@@ -665,7 +666,7 @@ __device__ __forceinline__ void store_f4_agent(float4* dst, const float4 v)
 
 // ONE thread: returns once *tk == want. `abort` is the word behind the last ticket: set by the first waiter that gives up, it lets every
 // later wait of the launch fall through at once (the launch ends within seconds instead of one time-out per waiter).
-__device__ __forceinline__ void ticket_spin(unsigned* const tk, const unsigned want, unsigned* const abort, unsigned* const err)
+__device__ __forceinline__ void ticket_spin(unsigned* const tk, const unsigned want, unsigned* const abort, unsigned* const err, const int timeout_us)
 {
     if (__hip_atomic_load(tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want) return;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -673,7 +674,7 @@ __device__ __forceinline__ void ticket_spin(unsigned* const tk, const unsigned w
         __builtin_amdgcn_s_sleep(2);
         if (__hip_atomic_load(tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want) return;
         if (__hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > kTicketTimeoutTicks) {   // never on a healthy run: flag it and go on
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 100ull * (unsigned long long)timeout_us) {   // (100-MHz ticks) never on a healthy run: flag it and go on
             __hip_atomic_store(abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return;
@@ -682,9 +683,9 @@ __device__ __forceinline__ void ticket_spin(unsigned* const tk, const unsigned w
 }
 
 // all threads of the workgroup: returns once the turn has come (thread 0 looks, the barrier tells the others)
-__device__ __forceinline__ void ticket_wait(unsigned* const tk, const unsigned want, unsigned* const abort, unsigned* const err)
+__device__ __forceinline__ void ticket_wait(unsigned* const tk, const unsigned want, unsigned* const abort, unsigned* const err, const int timeout_us)
 {
-    if (threadIdx.x == 0) ticket_spin(tk, want, abort, err);
+    if (threadIdx.x == 0) ticket_spin(tk, want, abort, err, timeout_us);
     __syncthreads();
 }
 
@@ -706,7 +707,7 @@ __device__ __forceinline__ void sym_add_i(M& t, const SymParams& p, const int ib
     const unsigned L = (unsigned)p.acc_lanes, lane = seq & (L - 1u), turn = seq / L;   // L is a power of two
     unsigned* const tk = p.tickets + (unsigned)I * L + lane;
     float4* const acc = p.acc + (size_t)lane * p.acc_stride;
-    ticket_wait(tk, turn, p.tickets + kTicketWords, p.err);
+    ticket_wait(tk, turn, p.tickets + kTicketWords, p.err, p.acc_timeout_us);
 #pragma unroll
     for (int k = 0; k < M::BPL; ++k) {
         const int i = ibase + k * 64;
@@ -731,7 +732,7 @@ __device__ __forceinline__ void sym_add_j(const float4* const sh, const SymParam
     const unsigned L = (unsigned)p.acc_lanes, lane = seq & (L - 1u), turn = seq / L;
     unsigned* const tk = p.tickets + (unsigned)J * L + lane;
     float4* const acc = p.acc + (size_t)lane * p.acc_stride;
-    ticket_wait(tk, turn, p.tickets + kTicketWords, p.err);
+    ticket_wait(tk, turn, p.tickets + kTicketWords, p.err, p.acc_timeout_us);
 #pragma unroll
     for (int e = threadIdx.x; e < B; e += 64 * W) {
         const int j = J * B + e;

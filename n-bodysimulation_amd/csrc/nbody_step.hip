@@ -193,6 +193,7 @@ void ticket_params(nbody_ctx* c, nbk::SymParams* sp, const float4* x, int i0, in
     sp->err = c->terr_dev;
     sp->acc_lanes = lanes;
     sp->acc_stride = n;
+    sp->acc_timeout_us = nbk::kTicketTimeoutUs;
 }
 
 int launch_run(nbody_ctx* c, const RunShape& y, const nbk::RunParams& p)
@@ -711,6 +712,11 @@ int nbody_step(nbody_ctx* c, nbody_float4* d_bodies, nbody_float4* d_acceleratio
             q.slabs = nullptr;
             q.nslab = 0;
             q.slab_stride = 0;
+        }
+        if (c->ticket_test_stall) {   // TEST hook, one shot: block 0's first ticket is held by nobody; a waiter gives up after 2 ms
+            c->ticket_test_stall = false;
+            HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->tickets), 0x7fffffff, 1, c->stream));
+            sp.acc_timeout_us = 2000;
         }
     } else {
         p.x = reinterpret_cast<const float4*>(d_bodies);

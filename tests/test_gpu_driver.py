@@ -187,6 +187,42 @@ def test_in_place_step_with_the_gpu_shared_between_processes(tmp_path):
           "us/step alone %.1f shared %s" % (alone["seconds"] / steps * 1e6, ["%.1f" % (o["seconds"] / steps * 1e6) for o in outs]))
 
 
+def test_in_place_block_sums_with_the_gpu_shared_between_processes(tmp_path):
+    """The ticket protocol of nbk::force_sym_ticket waits — for EARLIER tasks of the same launch only. With the GPU to itself every
+    workgroup's predecessor is resident or done; here three processes run the in-place step at the same time on the one GPU while a
+    fourth keeps it full, so a launch's workgroups start late, in bursts, or get their queue switched out as a whole. Every run must
+    finish (no wait may time out: the driver would report the error) and every result must be bit-identical to the same run alone —
+    the tickets fix the order of the additions, not the scheduling."""
+    n, steps = 200000, 6                        # 79 blocks of 2560: 3160 block-pair tasks per launch
+    base = [DRIVER, "--n", str(n), "--steps", str(steps), "--init", "plummer", "--dt", "0.01", "--no-equal-mass", "--inplace-sums", "on"]
+    alone = json.loads(_run([*base, "--dump", str(tmp_path / "alone")]).strip().splitlines()[-1])
+    assert alone["steps"] == steps
+    slabs = json.loads(_run([DRIVER, "--n", str(n), "--steps", str(steps), "--init", "plummer", "--dt", "0.01", "--no-equal-mass", "--inplace-sums", "off",
+                             "--dump", str(tmp_path / "slabs")]).strip().splitlines()[-1])
+    assert slabs["steps"] == steps
+    xa, xs = _f4(tmp_path / "alone.x.f4", n), _f4(tmp_path / "slabs.x.f4", n)
+    assert not np.array_equal(_f4(tmp_path / "alone.a.f4", n), _f4(tmp_path / "slabs.a.f4", n))      # another (fixed) order of the same block sums ...
+    assert np.abs(xa - xs)[:, :3].max() <= 1e-6                                                       # ... within rounding of the slab kernel
+    hog = subprocess.Popen([DRIVER, "--n", "131072", "--steps", "400", "--init", "plummer", "--dt", "0.01", "--quiet"],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    procs = [subprocess.Popen([*base, "--dump", str(tmp_path / f"shared{k}")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for k in range(3)]
+    try:
+        for p in procs:
+            out, err = p.communicate(timeout=240)
+            assert p.returncode == 0, err
+            assert json.loads(out.strip().splitlines()[-1])["steps"] == steps
+        hog.communicate(timeout=240)
+        assert hog.returncode == 0
+    finally:
+        for p in procs + [hog]:
+            if p.poll() is None:
+                p.kill()
+    for k in range(3):
+        for ext in ("x", "v", "a"):
+            assert np.array_equal(_f4(tmp_path / f"alone.{ext}.f4", n), _f4(tmp_path / f"shared{k}.{ext}.f4", n)), (k, ext)
+
+
 def test_compare_host_to_device_program():
     """compareHostToDevice in the reference's own terms: lock-step GPU/CPU steps, then the 1 % rule on
     positions, velocities and accelerations."""

@@ -1120,6 +1120,40 @@ def test_in_place_block_sums_vs_oracle(nb, oracle, n, kernel):
         assert np.abs(a1[n - m:] - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 1e-5
 
 
+def test_in_place_block_sums_abort_instead_of_hanging(nb):
+    """The failure path of the ticket protocol, exercised by the library's test hook (nbody_ctx_set_inplace_sums(ctx, 2): the next
+    in-place launch finds one ticket held by nobody and may wait 2 ms): the first waiter gives up, raises the abort word — every later
+    wait of the launch falls through at once, so the launch ENDS — and the host-mapped error word; the next synchronisation returns an
+    error that says what happened; the tickets are reset and the same context steps correctly afterwards."""
+    import time
+    n = 20001
+    x0 = nb.engine.seeded_bodies(n, 1, 3)
+    good = nb.engine.Simulation(x0, dt=0.01, eps2=0.002, kernel=nb.KERNEL_SYMMETRIC)
+    good.ctx.set_inplace_sums(1)
+    good.run(2)
+    want = good.state()
+    ctx = nb.engine.Context(dt=0.01, eps2=0.002, kernel=nb.KERNEL_SYMMETRIC)
+    ctx.set_inplace_sums(2)
+    assert ctx.step_info(n)["ticket"]
+    x = torch.from_numpy(x0).cuda()
+    v, a = torch.zeros_like(x), torch.zeros_like(x)
+    t0 = time.perf_counter()
+    ctx.step(x, a, v, 1)
+    with pytest.raises(nb.NBodyError) as e:
+        ctx.sync()
+    took = time.perf_counter() - t0
+    assert e.value.code == nb._lib.ERR_HIP and "waited more than" in str(e.value), str(e.value)
+    assert took < 5.0, took                                    # one 2-ms time-out, then everything falls through: not one time-out per waiter
+    ctx.sync()                                                 # reported once; the context is usable again
+    x.copy_(torch.from_numpy(x0).cuda())                       # (that step's sums were incomplete: restore the state, step again)
+    v.zero_()
+    a.zero_()
+    ctx.step(x, a, v, 2)
+    ctx.sync()
+    for got, w in zip((x, v, a), want):
+        assert np.array_equal(got.cpu().numpy(), w)
+
+
 def test_workspace_limit_at_a_quarter_keeps_the_symmetric_step_at_n262144(nb, oracle):
     """configs[2]'s size with the workspace capped at a quarter of the slab kernel's footprint: the step keeps the
     symmetric arithmetic — block pairs, sums in place, no workspace — instead of falling to the one-sided kernel (-30 %): within 1e-5 of
