@@ -664,6 +664,33 @@ __device__ __forceinline__ void store_f4_agent(float4* dst, const float4 v)
     __hip_atomic_store(q + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The same at 128 bits: one buffer_load/store_dwordx4 with the sc1 policy bit per float4 (HIP's scoped atomics stop at 64 bits; the raw
+// buffer intrinsics take the cache policy as an operand and leave the wait counters to the compiler). Coherence is what is needed here,
+// not single-copy atomicity of the 16 bytes: the ticket orders the accesses. `lane` = a buffer resource over one accumulation lane.
+typedef unsigned int nbk_u4 __attribute__((ext_vector_type(4)));
+typedef float nbk_f4 __attribute__((ext_vector_type(4)));
+constexpr int kBufferPolicySc1 = 16;   // aux / cache-policy operand of the gfx940+ buffer intrinsics: bit 0 sc0, bit 1 nt, bit 4 sc1
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t acc_lane_rsrc(float4* const base, const int n)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, n * (int)sizeof(float4), 0x00020000);
+}
+
+// (The 16 bytes are re-typed as a WHOLE vector. `__builtin_bit_cast(float, q.y)` on an element of an ext_vector_type value is
+//  mis-lowered by this clang — every element reads element 0 — which the ISA test caught as 22 one-dword loads where 22 wide ones belong.)
+__device__ __forceinline__ float4 load_f4_agent(const __amdgpu_buffer_rsrc_t lane, const int i)
+{
+    const nbk_f4 q = __builtin_bit_cast(nbk_f4, __builtin_amdgcn_raw_buffer_load_b128(lane, i * (int)sizeof(float4), 0, kBufferPolicySc1));
+    return make_float4(q.x, q.y, q.z, q.w);
+}
+
+__device__ __forceinline__ void store_f4_agent(const __amdgpu_buffer_rsrc_t lane, const int i, const float4 v)
+{
+    nbk_f4 q;
+    q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(nbk_u4, q), lane, i * (int)sizeof(float4), 0, kBufferPolicySc1);
+}
+
 // ONE thread: returns once *tk == want. `abort` is the word behind the last ticket: set by the first waiter that gives up, it lets every
 // later wait of the launch fall through at once (the launch ends within seconds instead of one time-out per waiter).
 __device__ __forceinline__ void ticket_spin(unsigned* const tk, const unsigned want, unsigned* const abort, unsigned* const err, const int timeout_us)
@@ -706,7 +733,7 @@ __device__ __forceinline__ void sym_add_i(M& t, const SymParams& p, const int ib
     if (EQ) t.scale(m0);
     const unsigned L = (unsigned)p.acc_lanes, lane = seq & (L - 1u), turn = seq / L;   // L is a power of two
     unsigned* const tk = p.tickets + (unsigned)I * L + lane;
-    float4* const acc = p.acc + (size_t)lane * p.acc_stride;
+    const __amdgpu_buffer_rsrc_t acc = acc_lane_rsrc(p.acc + (size_t)lane * p.acc_stride, p.ni);
     ticket_wait(tk, turn, p.tickets + kTicketWords, p.err, p.acc_timeout_us);
 #pragma unroll
     for (int k = 0; k < M::BPL; ++k) {
@@ -715,10 +742,10 @@ __device__ __forceinline__ void sym_add_i(M& t, const SymParams& p, const int ib
             float4 v = t.acc(k);
             v.w = 0.0f;
             if (turn) {   // (a lane's first contribution stores: the lanes need no clearing)
-                const float4 o = load_f4_agent(acc + i);
+                const float4 o = load_f4_agent(acc, i);
                 v.x += o.x; v.y += o.y; v.z += o.z;
             }
-            store_f4_agent(acc + i, v);
+            store_f4_agent(acc, i, v);
         }
     }
     ticket_pass(tk, seq + L >= (unsigned)p.nbi ? 0u : turn + 1u);   // the lane's last contribution of the nb: back to zero
@@ -731,7 +758,7 @@ __device__ __forceinline__ void sym_add_j(const float4* const sh, const SymParam
     constexpr int B = 64 * W * M::BPL;
     const unsigned L = (unsigned)p.acc_lanes, lane = seq & (L - 1u), turn = seq / L;
     unsigned* const tk = p.tickets + (unsigned)J * L + lane;
-    float4* const acc = p.acc + (size_t)lane * p.acc_stride;
+    const __amdgpu_buffer_rsrc_t acc = acc_lane_rsrc(p.acc + (size_t)lane * p.acc_stride, p.ni);
     ticket_wait(tk, turn, p.tickets + kTicketWords, p.err, p.acc_timeout_us);
 #pragma unroll
     for (int e = threadIdx.x; e < B; e += 64 * W) {
@@ -741,10 +768,10 @@ __device__ __forceinline__ void sym_add_j(const float4* const sh, const SymParam
             if (EQ) { v.x *= m0; v.y *= m0; v.z *= m0; }
             v.w = 0.0f;
             if (turn) {
-                const float4 o = load_f4_agent(acc + j);
+                const float4 o = load_f4_agent(acc, j);
                 v.x += o.x; v.y += o.y; v.z += o.z;
             }
-            store_f4_agent(acc + j, v);
+            store_f4_agent(acc, j, v);
         }
     }
     ticket_pass(tk, seq + L >= (unsigned)p.nbi ? 0u : turn + 1u);

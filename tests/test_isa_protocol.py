@@ -142,6 +142,10 @@ def test_the_checker_itself_sees_a_missing_drain():
 
 # ---- the second cross-workgroup protocol: block pairs with the sums added in place (nbk::force_sym_ticket) ------------------------------
 
+ACC_STORES = ("global_store_dwordx2", "buffer_store_dwordx4")   # how a kernel may write a partial sum back: agent-scope 64-bit halves, or one 128-bit buffer store
+ACC_LOADS = ("global_load_dwordx2", "buffer_load_dwordx4", "buffer_load_dwordx3")   # (x, y, z of a sum are what is added: the compiler may leave w unread)
+
+
 def _ticket_kernels(isa):
     return sorted(n for n in isa if "force_sym_ticket" in n)
 
@@ -155,7 +159,7 @@ def check_ticket_hand_over(name, insns, waves):
         if op != "global_store_dword" or "sc1" not in args or "sc0" in args:
             continue
         back = insns[max(0, k - 60):k]
-        last_acc = max((q for q, (_, o, a, _) in enumerate(back) if o == "global_store_dwordx2" and "sc1" in a), default=None)
+        last_acc = max((q for q, (_, o, a, _) in enumerate(back) if o in ACC_STORES and "sc1" in a), default=None)
         spin = max((q for q, (_, o, _, _) in enumerate(back) if o == "s_memrealtime"), default=None)
         if spin is not None and (last_acc is None or spin > last_acc):
             continue                                             # the abort flag, raised inside the spin loop: not a hand-over
@@ -186,11 +190,14 @@ def test_in_place_block_pair_kernels_move_their_sums_at_agent_scope(isa):
     global_store of partial sums), and its spin loop looks at the tickets with agent-scope loads."""
     for name in _ticket_kernels(isa):
         insns = isa[name]
-        stores = [(op, args) for _, op, args, _ in insns if op.startswith("global_store")]
+        stores = [(op, args) for _, op, args, _ in insns if op.startswith(("global_store", "buffer_store", "flat_store"))]
         assert stores and all("sc1" in args for _, args in stores), (name, [s for s in stores if "sc1" not in s[1]][:3])
-        acc_stores = [1 for op, args in stores if op == "global_store_dwordx2"]
-        acc_loads = [1 for _, op, args, _ in insns if op == "global_load_dwordx2" and "sc1" in args]
-        assert len(acc_stores) >= 2 * 2 * (10 + 1) and len(acc_loads) >= 2 * 2 * (10 + 1), (name, len(acc_stores), len(acc_loads))   # 2 halves x (general, equal-mass) x (10 I-side unrolled + the J-side loop)
+        acc_stores = [1 for op, args in stores if op in ACC_STORES]
+        acc_loads = [1 for _, op, args, _ in insns if op in ACC_LOADS and "sc1" in args]
+        per_sum = 1 if any(op == "buffer_store_dwordx4" for op, _ in stores) else 2          # one 128-bit access per partial sum, or two 64-bit halves
+        want = per_sum * 2 * (10 + 1)                                                         # x (general, equal-mass) x (10 I-side unrolled + the J-side loop)
+        assert len(acc_stores) >= want and len(acc_loads) >= want, (name, len(acc_stores), len(acc_loads), want)
+        assert not any(op in ACC_LOADS and "sc1" not in args and op.startswith("buffer") for _, op, args, _ in insns), name   # no plain access to the lanes
         polls = [1 for _, op, args, _ in insns if op == "global_load_dword" and "sc1" in args]
         assert len(polls) >= 4, (name, len(polls))
         assert any(op == "s_memrealtime" for _, op, _, _ in insns) and any(op == "s_sleep" for _, op, _, _ in insns), name   # bounded, polite spin
@@ -201,6 +208,8 @@ def test_the_ticket_checker_sees_a_missing_drain():
         return [(0x100 + 4 * k, op, args, None) for k, (op, args) in enumerate(lines)]
     good = mk([("global_store_dwordx2", "v[0:1], v[2:3], off sc1"), ("s_waitcnt", "vmcnt(0)"), ("s_barrier", ""), ("global_store_dword", "v0, v1, s[2:3] sc1")])
     assert check_ticket_hand_over("good", good, 4) == 1
+    wide = mk([("buffer_store_dwordx4", "v[0:3], v4, s[4:7], 0 offen sc1"), ("s_waitcnt", "vmcnt(0)"), ("s_barrier", ""), ("global_store_dword", "v0, v1, s[2:3] sc1")])
+    assert check_ticket_hand_over("wide", wide, 4) == 1
     no_drain = mk([("global_store_dwordx2", "v[0:1], v[2:3], off sc1"), ("s_waitcnt", "lgkmcnt(0)"), ("s_barrier", ""), ("global_store_dword", "v0, v1, s[2:3] sc1")])
     with pytest.raises(AssertionError):
         check_ticket_hand_over("no_drain", no_drain, 4)
