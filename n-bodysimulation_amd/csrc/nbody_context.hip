@@ -110,6 +110,7 @@ int ensure_tickets(nbody_ctx* c)
         return fail(NBODY_ERR_NOMEM, "cannot allocate the ticket words: %s", hipGetErrorString(e));
     }
     HIP_TRY(hipMemsetAsync(c->tickets, 0, bytes, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // once per context: the zeroes are there whichever stream the context launches on later
     return NBODY_OK;
 }
 

@@ -906,10 +906,12 @@ int nbody_simulate(nbody_float4* d_bodies, nbody_float4* d_accelerations, nbody_
     }
     // simulate() is synchronous (kernel.cu:644). Waiting for the launch's own word costs about 4 us less per call than
     // hipStreamSynchronize (profiles/r04_sync_probe_*.txt); the stream synchronisation stays as the backstop (and reports errors).
-    if (wait_host_word(c)) return NBODY_OK;
+    // (either way the step is complete here; a ticket wait that timed out inside it — the in-place block-pair kernel, never on a healthy
+    //  run — is this call's error, as a failed launch would be)
+    if (wait_host_word(c)) return ticket_error(c);
     ON_DEVICE(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return NBODY_OK;
+    return ticket_error(c);
 }
 
 // The older snapshot's boundary (Sim-Without-OpenGL-Integration/kernel.cuh:5, kernel.cu:85-125): HOST
