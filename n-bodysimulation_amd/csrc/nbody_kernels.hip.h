@@ -638,8 +638,9 @@ enum SymCase : int { kSymGeneral = 0, kSymSquare = 1, kSymRect = 2, kSymTicket =
 //     tickets[K][lane] == s / L, adds (a lane's first contribution stores), drains its stores (s_waitcnt vmcnt(0) in every wave, then
 //     the workgroup barrier), and hands the ticket on; a lane's last contribution leaves its ticket at zero for the next launch. With
 //     L = 1 the one lane is the acceleration array itself: no workspace at all;
-//   * data moves through agent-scope atomics (global_load/store_dwordx2 sc1): the eight XCDs' L2s are not coherent for ordinary
-//     accesses, and an agent-scope load is defined to see an agent-scope store that completed before it was issued.
+//   * the sums move through AGENT-SCOPE accesses (buffer_load_dwordx3 / buffer_store_dwordx4 with the sc1 policy bit; the tickets
+//     through agent-scope 32-bit atomics): the eight XCDs' L2s are not coherent for ordinary accesses, and an agent-scope load is
+//     defined to see an agent-scope store that completed before it was issued.
 // A waiter only ever waits for a task EARLIER in the list. Workgroups of a grid start in index order, so the earliest unfinished task
 // is always resident and never waits: no deadlock; and should a wait exceed ten seconds all the same (a stopped predecessor), the
 // waiter raises the host-mapped error word and goes on — a wrong, flagged result instead of a hung GPU (the host checks the word at
