@@ -10,7 +10,7 @@ test-gpu:
 bench:
 	python bench.py
 # developer probes (tools/README.md); binaries land in build/ (git-ignored, travels with gpurun)
-TOOLS := symbench balbench kbench f64bench f64shapes bal_sim dp_mb valu_mb mfma_mb rsq64_probe pkbank_mb
+TOOLS := symbench balbench kbench f64bench f64shapes bal_sim dp_mb valu_mb mfma_mb rsq64_probe pkbank_mb clock_probe
 tools: build
 	mkdir -p build
 	for t in $(TOOLS); do hipcc -O3 -std=c++17 --offload-arch=gfx950 -I n-bodysimulation_amd/csrc -I include tools/$$t.hip -o build/$$t || exit 1; done

@@ -133,7 +133,7 @@ def test_every_global_kernel_of_the_product_header_is_instantiated_by_the_librar
     assert probes and not (probes & compiled), f"tools-only kernels found in the library: {sorted(probes & compiled)}"
 
 
-@pytest.mark.parametrize("tool", ["symbench", "balbench", "kbench", "f64bench", "f64shapes", "bal_sim", "sync_probe", "dp_mb", "valu_mb", "mfma_mb", "rsq64_probe", "pkbank_mb"])
+@pytest.mark.parametrize("tool", ["symbench", "balbench", "kbench", "f64bench", "f64shapes", "bal_sim", "sync_probe", "dp_mb", "valu_mb", "mfma_mb", "rsq64_probe", "pkbank_mb", "clock_probe"])
 def test_developer_probes_still_compile_against_the_product_headers(tool):
     """tools/*.hip (the measured alternatives and the instruction-cost probes) are kept because DESIGN.md quotes their results: they must
     keep compiling against the product's device header and C-ABI as those move (front end only, host and gfx950 passes; no GPU needed)."""
