@@ -222,9 +222,10 @@ int nbody_ctx_equal_mass_verdict(nbody_ctx* ctx, int* scanned, int* uniform, flo
 /* The symmetric kernels keep one slab of partial sums per block of bodies (nb x n x 16 B: 412 MiB at N = 262144, 6.4 GiB at
  * N = 1048576, growing as N^2/B). The launch-shape choice only uses a slab decomposition whose workspace fits a cap:
  * min(96 GiB, half of the device memory that is free, `bytes` if non-zero); beyond it — or when the allocation itself fails —
- * a whole step keeps the symmetric arithmetic and adds the block sums IN PLACE instead (nbody_ctx_set_inplace_sums below: no
- * workspace at all); nbody_accel_range on a square block falls back to the next smaller footprint and finally to the one-sided
- * kernel (<= 64 slabs, about 30 % slower at large N); nbody_accel_cross cuts its source run into pieces. Never an error.
+ * a whole step, and nbody_accel_range on a square block, keep the symmetric arithmetic and add the block sums IN PLACE instead
+ * (nbody_ctx_set_inplace_sums below: a few accumulation lanes, or no workspace at all); only a cap below two lanes of
+ * nbody_accel_range ends in the one-sided kernel (<= 64 slabs, about 30 % slower at large N); nbody_accel_cross cuts its source
+ * run into pieces. Never an error.
  * bytes = 0: automatic. fail_above != 0 is a TEST hook: the shape choice ignores `bytes`, and every workspace allocation larger
  * than `bytes` fails as if the device were out of memory (exercises the fallback path without exhausting a 288 GB device). */
 int nbody_ctx_set_workspace_limit(nbody_ctx* ctx, size_t bytes, int fail_above);

@@ -445,6 +445,12 @@ int nbody_ctx_launch_info(nbody_ctx* c, int n_targets, int n_sources, int* jspli
         if (lds_bytes) *lds_bytes = y.block * (int)sizeof(float4);
         return NBODY_OK;
     }
+    if (n_targets == n_sources && ticket_wanted(c, n_targets, &y) && ticket_lanes(c, n_targets, y.nb) > 1) {   // block sums added in place
+        if (jsplit) *jsplit = ticket_lanes(c, n_targets, y.nb);
+        if (blocks) *blocks = y.grid;
+        if (lds_bytes) *lds_bytes = y.block * (int)sizeof(float4);
+        return NBODY_OK;
+    }
     const Shape s = resolve_shape(c, n_targets, n_sources);
     if (jsplit) *jsplit = s.jsplit;
     if (blocks) *blocks = s.blocks_x * s.jsplit;

@@ -295,6 +295,43 @@ int accel_impl(nbody_ctx* c, const nbody_float4* d_bodies, nbody_float4* d_acc_o
 {
     const int nt = i1 - i0;
     ON_DEVICE(c);
+    // A square block with the block sums added IN PLACE (nbk::force_sym_ticket) into 2 ... 8 accumulation lanes in the workspace, then one
+    // slab sum over the lanes: where the slab workspace of the symmetric kernels does not fit the cap, or where in-place sums were asked
+    // for. (One lane would be the output array itself, which cannot ALSO hold what `accumulate` is to add to: a cap below two lanes
+    // leaves *done false and the one-sided kernel runs.)
+    auto in_place = [&](bool* done) -> int {
+        *done = false;
+        SymShape ty{};
+        if (!(i0 == j0 && i1 == j1 && !wrap && ticket_wanted(c, nt, &ty))) return NBODY_OK;
+        int lanes = ticket_lanes(c, nt, ty.nb);
+        while (lanes > 1 && ensure_slabs(c, (size_t)lanes * nt * sizeof(float4)) != NBODY_OK) lanes /= 2;
+        if (lanes <= 1) return NBODY_OK;
+        if (int rc = ensure_tickets(c)) return rc;
+        if (int rc = ticket_error(c)) return rc;
+        nbk::SymParams sp{};
+        ticket_params(c, &sp, reinterpret_cast<const float4*>(d_bodies), i0, nt, ty, static_cast<float4*>(c->slabs), lanes);
+        if (int rc = eq_scan(c, 0, sp.x, i0, nt, 0, 0, 0, &sp.eqm, &sp.eq_gen)) return rc;
+        if (int rc = launch_ticket(c, ty, sp, true)) return rc;
+        nbk::ReduceParams r{};
+        r.out = reinterpret_cast<float4*>(d_acc_out);
+        r.slabs = static_cast<const float4*>(c->slabs);
+        r.nslab = lanes;
+        r.slab_stride = nt;
+        r.n = nt;
+        r.accumulate = accumulate ? 1 : 0;
+        nbk::reduce_slabs<<<(nt + nbk::kWG - 1) / nbk::kWG, nbk::kWG, 0, c->stream>>>(r);
+        HIP_TRY(hipGetLastError());
+        *done = true;
+        return NBODY_OK;
+    };
+    if (c->inplace_sums == 1) {   // asked for: ahead of unit runs / block pairs with slabs (balanced runs keep their sizes)
+        BalShape by0{};
+        if (!(i0 == j0 && i1 == j1 && !wrap && bal_wanted(c, nt, &by0))) {
+            bool done = false;
+            if (int rc = in_place(&done)) return rc;
+            if (done) return NBODY_OK;
+        }
+    }
     // the symmetric decompositions need nb (or max_slabs) slabs of nt bodies: when that allocation fails the cap is lowered and
     // the shape resolved again (a smaller footprint, finally the one-sided kernel)
     for (int attempt = 0; attempt < 16; ++attempt) {
@@ -368,6 +405,11 @@ int accel_impl(nbody_ctx* c, const nbody_float4* d_bodies, nbody_float4* d_acc_o
         nbk::reduce_slabs<<<(nt + nbk::kWG - 1) / nbk::kWG, nbk::kWG, 0, c->stream>>>(r);
         HIP_TRY(hipGetLastError());
         return NBODY_OK;
+    }
+    {
+        bool done = false;
+        if (int rc = in_place(&done)) return rc;
+        if (done) return NBODY_OK;
     }
     const Shape s = resolve_shape(c, nt, j1 - j0);
     nbk::ForceParams p{};

@@ -1120,6 +1120,47 @@ def test_in_place_block_sums_vs_oracle(nb, oracle, n, kernel):
         assert np.abs(a1[n - m:] - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 1e-5
 
 
+def test_accel_range_on_a_square_block_keeps_the_symmetric_arithmetic_under_a_cap(nb, oracle):
+    """nbody_accel_range(targets == sources) — the piece the sharded step's own-block pass is made of — under a workspace cap that no slab
+    decomposition fits: the block sums are added in place into a few lanes and summed (2 … 8 lanes of 16·n bytes), `accumulate` included;
+    only a cap below two lanes ends in the one-sided kernel. Same tolerances as the unconstrained evaluation, bit-identical run to run."""
+    n, i0 = 30000, 1000                       # a block that does not start at body 0
+    nt = 24000
+    x0 = nb.engine.seeded_bodies(n, 1, 77)
+    x = torch.from_numpy(x0).cuda()
+    truth = oracle.accel_range(x0, i0, i0 + 1024, i0, i0 + nt, eps2=0.002, f64acc=True)
+    free = nb.engine.Context(dt=0.01, eps2=0.002)
+    ref = torch.zeros((nt, 4), device="cuda")
+    free.accel_range(x, ref, i0, i0 + nt, i0, i0 + nt)
+    free.sync()
+    ref = ref.cpu().numpy()
+    scale = np.abs(ref[:, :3]).max()
+    for limit, want_lanes in ((8 * nt * 16, 8), (5 * nt * 16, 4), (2 * nt * 16, 2)):
+        ctx = nb.engine.Context(dt=0.01, eps2=0.002)
+        ctx.set_workspace_limit(limit)
+        js = ctx.launch_info(nt, nt)["jsplit"]
+        assert js == want_lanes, (limit, js)
+        outs = []
+        for rep in range(2):
+            out = torch.full((nt, 4), 5.0, device="cuda")
+            ctx.accel_range(x, out, i0, i0 + nt, i0, i0 + nt)
+            ctx.sync()
+            outs.append(out.cpu().numpy())
+        assert np.array_equal(outs[0], outs[1])
+        assert np.abs(outs[0] - ref)[:, :3].max() / scale <= 2e-6 and np.all(outs[0][:, 3] == 0)
+        assert np.abs(outs[0][:1024] - truth)[:, :3].max() / np.abs(truth[:, :3]).max() <= 1e-5
+        acc = torch.from_numpy(ref.copy()).cuda()
+        ctx.accel_range(x, acc, i0, i0 + nt, i0, i0 + nt, accumulate=True)          # adds to what the array holds
+        ctx.sync()
+        assert np.abs(acc.cpu().numpy() - 2.0 * ref)[:, :3].max() / scale <= 4e-6
+    tiny = nb.engine.Context(dt=0.01, eps2=0.002)
+    tiny.set_workspace_limit(nt * 16)           # not even two lanes: the one-sided kernel (its <= 64 slabs are always allowed)
+    out = torch.zeros((nt, 4), device="cuda")
+    tiny.accel_range(x, out, i0, i0 + nt, i0, i0 + nt)
+    tiny.sync()
+    assert np.abs(out.cpu().numpy() - ref)[:, :3].max() / scale <= 1e-5
+
+
 def test_in_place_block_sums_abort_instead_of_hanging(nb):
     """The failure path of the ticket protocol, exercised by the library's test hook (nbody_ctx_set_inplace_sums(ctx, 2): the next
     in-place launch finds one ticket held by nobody and may wait 2 ms): the first waiter gives up, raises the abort word — every later
