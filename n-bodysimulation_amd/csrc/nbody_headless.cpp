@@ -62,11 +62,14 @@ static bool read_file(const std::string& path, void* p, size_t bytes)
 
 int main(int argc, char** argv)
 {
-    int n = N_BODIES, steps = 10, kernel = NBODY_KERNEL_FAST, sync_each = 0, interactive = 0, json = 1, ngpu = 1, timeout_s = 900, autotune = 0, equal_mass = -1, inplace_sums = -1;
+    int n = N_BODIES, steps = 10, kernel = NBODY_KERNEL_FAST, sync_each = 0, interactive = 0, json = 1, ngpu = 1, timeout_s = 900, autotune = 0, equal_mass = -1, inplace_sums = -1, clock = 0;
     std::string transport = "rccl";   // --ngpu: rccl (librccl, one GPU per rank) | local (hipMemcpyPeerAsync pulls between the rank threads, no RCCL)
     bool share_devices = false;
     bool f64 = false, force_shard = false;
     long steps_done = 0;
+    double force_ms = 0.0;
+    int force_launches = 0;
+    nbody_clock_report clk{};
     float dt = DT, eps2 = EPS2;
     unsigned long long seed = 12345;
     std::string init = "libc", dump, load;
@@ -95,6 +98,7 @@ int main(int argc, char** argv)
         else if (a == "--sync-each-step") sync_each = 1;
         else if (a == "--no-equal-mass") equal_mass = 0;  // nbody_ctx_set_equal_mass(0): the general pair arithmetic whatever the masses
         else if (a == "--inplace-sums") { std::string q = val(); if (q != "auto" && q != "on" && q != "off") die("--inplace-sums auto|on|off"); inplace_sums = q == "on" ? 1 : q == "off" ? 0 : -1; }   // nbody_ctx_set_inplace_sums: block sums added in place (no slab workspace)
+        else if (a == "--clock") clock = 1;              // nbody_ctx_timing(ctx, 2): the force launches' event time, shader cycles and the shader clock under load in the JSON line (queued single-GPU stepping)
         else if (a == "--autotune") autotune = 1;        // measure the decompositions on this device first (single GPU, fast kernel)
         else if (a == "--interactive") interactive = 1;
         else if (a == "--quiet") json = 0;
@@ -342,10 +346,16 @@ int main(int argc, char** argv)
             }
         }
     } else {
+        if (clock) ok(nbody_ctx_timing(ctx, 2));
         ok(nbody_step(ctx, (nbody_float4*)d_bodies, (nbody_float4*)d_accelerations, (nbody_float4*)d_velocity, n, steps));
         ok(nbody_ctx_sync(ctx));
     }
     secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (clock && !sync_each) {
+        ok(nbody_ctx_timing_read(ctx, &force_ms, &force_launches));
+        ok(nbody_ctx_clock_read(ctx, &clk));
+        ok(nbody_ctx_timing(ctx, 0));
+    }
     std::printf("Simulation complete\n");                // main.cpp:158
     if (sync_each) ok(nbody_ctx_autotuned(ctx, n, &autotuned_choice, nullptr, nullptr));   // what simulate()'s one-off measurement decided for this size (-1: none)
     if (sync_each) ok(nbody_ctx_fused_inplace_stats(ctx, &inplace_fallback_waves));   // waves of the in-place step that wrote to the spare array (0 when the GPU was ours alone)
@@ -367,6 +377,11 @@ int main(int argc, char** argv)
                       n, steps_done + steps, dt, eps2, f64 ? "f64" : "f32", ngpu, f64 ? "; double4 x,y,z,w LE (.f8)" : "");
         if (!write_file(dump + ".json", hdr, std::strlen(hdr))) die("cannot write " + dump + ".json");
     }
+    if (json && clock && clk.launches > 0)   // what clock the line below was measured at: cycles = the code, sclk = the box
+        std::printf("{\"clock\": {\"force_kernel_ms_per_launch\": %.6f, \"launches\": %d, \"kernel_cycles_per_launch\": %.6g, \"sclk_mhz_under_load\": %.1f, "
+                    "\"sclk_mhz_slowest_xcd\": %.1f, \"sclk_mhz_fastest_xcd\": %.1f, \"ms_per_launch_by_device_clock\": %.6f}}\n",
+                    force_launches ? force_ms / force_launches : 0.0, clk.launches, clk.cycles_per_launch, clk.sclk_mhz, clk.sclk_mhz_min_xcd, clk.sclk_mhz_max_xcd,
+                    clk.ticks_per_launch * 1e-5);
     if (json) {
         const double pairs = (double)n * (double)n * steps;
         std::printf("{\"n\": %d, \"steps\": %d, \"dt\": %.9g, \"eps2\": %.9g, \"kernel\": \"%s\", \"ngpu\": %d, \"seconds\": %.6f, \"pairs_per_s\": %.6g, "

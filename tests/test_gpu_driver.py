@@ -187,6 +187,19 @@ def test_in_place_step_with_the_gpu_shared_between_processes(tmp_path):
           "us/step alone %.1f shared %s" % (alone["seconds"] / steps * 1e6, ["%.1f" % (o["seconds"] / steps * 1e6) for o in outs]))
 
 
+def test_headless_says_what_clock_it_ran_at():
+    """nbody_headless --clock: the C++ driver's line read against the clock it was measured at (nbody_ctx_timing(ctx, 2) /
+    nbody_ctx_clock_read through the C-ABI from a g++-built program): one record per force launch, cycles / sclk = the launch's duration."""
+    out = _run([DRIVER, "--n", "65536", "--steps", "12", "--init", "plummer", "--dt", "0.01", "--clock"])
+    lines = [json.loads(ln) for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 2 and "clock" in lines[0] and lines[1]["steps"] == 12
+    c = lines[0]["clock"]
+    assert c["launches"] == 12 and 800 < c["sclk_mhz_under_load"] < 2600
+    assert c["sclk_mhz_slowest_xcd"] <= c["sclk_mhz_under_load"] <= c["sclk_mhz_fastest_xcd"]
+    assert abs(c["kernel_cycles_per_launch"] / (c["sclk_mhz_under_load"] * 1e3) - c["ms_per_launch_by_device_clock"]) < 1e-4
+    assert c["force_kernel_ms_per_launch"] <= c["ms_per_launch_by_device_clock"] * 1.002 < c["force_kernel_ms_per_launch"] + 0.06
+
+
 def test_in_place_block_sums_with_the_gpu_shared_between_processes(tmp_path):
     """The ticket protocol of nbk::force_sym_ticket waits — for EARLIER tasks of the same launch only. With the GPU to itself every
     workgroup's predecessor is resident or done; here three processes run the in-place step at the same time on the one GPU while a
