@@ -121,6 +121,8 @@ inline bool bal_plan(int n, int bpl, int workers_target, int wv, BalLayout* out)
 // Device words of the in-place protocol.
 // kFusedFinished counts workgroups in its low half and fall-back waves in its high half (a wave's mark precedes its workgroup's
 // count, so the workgroup that completes the count reads both in the one value its atomic returns: one round trip, not two).
+enum FusedSync : int { kFusedReaders = 0, kFusedFinished = 1, kFusedFallbacksTotal = 2, kFusedSyncWords = 4 };
+
 // The clock stamps around a timed force launch (nbk::clock_begin / clock_end). s_memtime is a free-running counter of SHADER cycles
 // (MI355X_MICROARCH.md: "tick = shader cycle") kept PER CU: the CUs of one XCD count at the same rate from different starting values
 // (measured, tools/clock_probe.hip: same-XCD CUs agree to 1e-6 over a launch, tail idleness included; different XCDs run 1.5-2 % apart),
@@ -141,7 +143,5 @@ constexpr int kClockEndWgs = 256;    // workgroups of the stamp behind: lands on
 
 constexpr int kTicketMaxLanes = 8;    // nbk::force_sym_ticket: accumulation lanes per body at most
 constexpr int kTicketWords = 2048 * kTicketMaxLanes;   // one ticket per (block, lane): nbi::kSymMaxSlabs blocks; the word behind them is the launch's abort flag
-
-enum FusedSync : int { kFusedReaders = 0, kFusedFinished = 1, kFusedFallbacksTotal = 2, kFusedSyncWords = 4 };
 
 }  // namespace nbk
