@@ -176,9 +176,12 @@ def spawn_ranks(gpus: int) -> int:
     env.setdefault("OMP_NUM_THREADS", "1")              # what the launcher would set itself, with a warning
     child = {"proc": None, "pending": None}
 
+    import ctypes
+    libc = ctypes.CDLL("libc.so.6", use_errno=True)       # loaded HERE: nothing is imported between fork and exec (this process may have threads)
+    sigterm = int(signal.SIGTERM)
+
     def die_with_parent():                               # in the child, before exec: a parent that is SIGKILLed takes the launcher with it
-        import ctypes
-        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, int(signal.SIGTERM))   # PR_SET_PDEATHSIG
+        libc.prctl(1, sigterm)                           # PR_SET_PDEATHSIG
 
     def signal_group(signum) -> None:
         proc = child["proc"]
