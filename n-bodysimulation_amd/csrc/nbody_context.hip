@@ -280,7 +280,7 @@ const char* nbody_last_error(void) { return g_err; }
 
 const char* nbody_version(void)
 {
-    return "nbody_hip 0.5 gfx950 fast=symmetric-dpp(w4,bpl10)+equal-mass-path|symmetric-balanced-runs(8k-45k)|fused-step(<=8k;simulate:in-place,stores-drained+host-word)|onesided-lds-packed(bpl4,tile2048,u8) strict=ieee-seq f64=symmetric-dpp(w4,bpl6)+equal-mass-path|lds";
+    return "nbody_hip 0.6 gfx950 fast=symmetric-dpp(w4,bpl10)+equal-mass-path+sums-in-place-beyond-the-workspace-cap(tickets,8-lanes)|symmetric-balanced-runs(8k-45k)|fused-step(<=8k;simulate:in-place,stores-drained+host-word)|onesided-lds-packed(bpl4,tile2048,u8) strict=ieee-seq f64=symmetric-dpp(w4,bpl6)+equal-mass-path|lds";
 }
 
 int nbody_device_count(int* count)
